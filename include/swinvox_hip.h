@@ -1,0 +1,170 @@
+/*
+ * swinvox_hip.h -- C ABI of libswinvox_hip.so, the MI355X (gfx950) implementation of the SwinVox
+ * Encoder -> Decoder -> Merger -> Refiner forward/backward path.
+ *
+ * The reference (SandeepaInduwaraSamaranayake/SwinVox) has no FFI layer: its hot path is a chain of
+ * stock PyTorch operators dispatched from its models/ package.  Each entry point below replaces one operator
+ * class of that chain; the comment above every group cites the
+ * reference file:line whose operator it stands in for.  The host side (the swinvox_amd/models package) binds
+ * these through ctypes and mirrors the reference's nn.Module surface.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless said otherwise; the library never allocates,
+ *     frees or retains memory (all buffers, including workspaces, are owned by the caller);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only enqueues work;
+ *   - return value: 0 on success, <0 on error (SV_ERR_*); sv_last_error() returns a message for the
+ *     calling thread; no entry point aborts the process;
+ *   - activations are channels-last: 2-D maps [N,H,W,C], 3-D grids [N,D,H,W,C], token lists [rows,C];
+ *     a row stride `ld*` (in elements) lets a call read/write a column slice of a wider buffer;
+ *   - re-entrant and thread-safe: no global mutable state besides the thread-local error string.
+ */
+#ifndef SWINVOX_HIP_H
+#define SWINVOX_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SV_OK 0
+#define SV_ERR_INVALID (-1)
+#define SV_ERR_LAUNCH (-2)
+
+enum { SV_ACT_NONE = 0, SV_ACT_RELU = 1, SV_ACT_GELU = 2, SV_ACT_LRELU = 3 };
+enum { SV_MATH_F32 = 0, SV_MATH_BF16 = 1 }; /* MFMA input type of the contraction kernels; I/O and accumulation stay fp32 */
+
+const char* sv_last_error(void);
+int sv_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Contraction engine (implicit GEMM on MFMA): stands in for nn.Linear / nn.Conv2d / nn.Conv3d /
+ * nn.ConvTranspose3d forward, data-gradient and weight-gradient.  Reference call sites:
+ * timm Linear layers behind models/swin_transformer.py:78; models/encoder.py:22-23,36,41-111;
+ * models/cross_view_attention.py:38,46,49-53; models/decoder.py:24-46; models/merger.py:20-54;
+ * models/refiner.py:21-70.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sv_geom {
+  int N;              /* images (or rows for a Linear: N = rows, all grids 1x1x1) */
+  int Di, Hi, Wi;     /* grid of the GATHERED tensor  */
+  int Do, Ho, Wo;     /* grid of the PRODUCED tensor  */
+  int Ci, Co;         /* channels of gathered / produced tensor (in-memory, i.e. including padding) */
+  int kd, kh, kw;     /* kernel extent */
+  int sd, sh, sw;     /* stride */
+  int pd, ph, pw;     /* padding */
+  int ldi;            /* element stride between consecutive positions of the gathered tensor (>= Ci) */
+} sv_geom;
+
+typedef struct sv_epilogue {
+  const float* bias;     /* [Co] or NULL */
+  const float* residual; /* same positions as the output, row stride ldr, or NULL:  out = residual + scale*val */
+  int ldr;
+  const float* row_scale; /* optional per-image scale of val before the residual add (drop-path), index = row / rows_per_scale */
+  int rows_per_scale;
+  float* pre_act;        /* optional: receives val (after bias, before activation), same layout as out */
+  float* stats;          /* optional [2*Co]: atomically accumulates sum and sum-of-squares of the stored output per channel */
+  int act;               /* SV_ACT_* applied to val (after bias) */
+  float slope;           /* LeakyReLU slope */
+  const float* act_grad_src; /* optional: val *= act'(act_grad_src[pos]) (backward through an activation), layout of out */
+  int act_grad_kind;     /* SV_ACT_* of that activation */
+  int ldc;               /* output row stride (elements) */
+  int col_off;           /* first output column */
+} sv_epilogue;
+
+/* gather form:  out[o, co] = sum_{tap,ci} in[o*s - p + tap, ci] * w[co, tap, ci]      (conv forward; tconv data-grad; Linear) */
+int sv_conv_gather(const float* in, const float* w_packed, float* out, const sv_geom* g, const sv_epilogue* e,
+                   int math, void* stream);
+/* scatter-as-gather form: out[o, co] = sum_{tap,ci : (o+p-tap)%s==0} in[(o+p-tap)/s, ci] * w[co, tap, ci]
+ * (transposed-conv forward; strided-conv data-grad), decomposed per output parity class            */
+int sv_tconv_gather(const float* in, const float* w_packed, float* out, const sv_geom* g, const sv_epilogue* e,
+                    int math, void* stream);
+/* weight gradient: dw[ca, cg, tap] += sum_r anchor[r, ca] * gathered[r*s - p + tap, cg]   (fp32 atomics; dw pre-zeroed
+ * or holding a running sum).  g->Do.. = anchor grid, g->Di.. = gathered grid, g->Co = anchor channels (row stride lda),
+ * g->Ci = gathered channels (stride g->ldi); only cg < cg_valid is written; dw index = (ca*cg_valid + cg)*taps + tap.     */
+int sv_conv_wgrad(const float* anchor, int lda, const float* gathered, float* dw, const sv_geom* g, int cg_valid,
+                  int math, void* stream);
+/* dst[a][t][b] (b padded with zeros to bpad) from src[a][b][t]  (swap=0), or dst[b][t][a..apad] (swap=1) */
+int sv_pack_weight(const float* src, float* dst, int A, int B, int T, int swap, int pad_to, void* stream);
+/* per-column sum over rows: out[c] (+)= sum_r x[r*ld + c]  (bias gradients) */
+int sv_colsum(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisation.  Token LayerNorm = timm norm1/norm2/patch_embed.norm/downsample.norm (eps 1e-5); with
+ * merge_H/merge_W > 0 the rows are the PatchMerging 2x2 gather (order h0w0,h1w0,h0w1,h1w1) of a
+ * [I,merge_H,merge_W,C/4] map.  Image LayerNorm = nn.LayerNorm([C,H,W]) + Dropout(0.05) of
+ * models/swin_transformer.py:64-69,82-89 on NHWC data with the affine pre-transposed to [HW,C].
+ * BatchNorm = nn.BatchNorm2d/3d of models/encoder.py, cross_view_attention.py:56, decoder.py, merger.py,
+ * refiner.py on channels-last [M,C] (biased batch variance, unbiased running update, eps 1e-5).
+ * ---------------------------------------------------------------------------------------------- */
+int sv_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                     long long rows, int C, float eps, int merge_H, int merge_W, void* stream);
+int sv_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                     float* dx, float* dgamma, float* dbeta, long long rows, int C, int merge_H, int merge_W,
+                     int accumulate_dx, void* stream);
+size_t sv_ln_image_workspace_floats(int I, int L);
+int sv_ln_image_fwd(const float* x, const float* w, const float* b, float* y, float* meanrstd, float* workspace,
+                    int I, int L, float eps, float drop_p, uint32_t seed, void* stream);
+int sv_ln_image_bwd(const float* dy, const float* x, const float* w, const float* meanrstd, float* dx, float* dw,
+                    float* db, float* sums_ws, int I, int L, float drop_p, uint32_t seed, void* stream);
+int sv_bn_stats(const float* x, long long M, int C, int ld, float* sums, void* stream);
+int sv_bn_finalize(const float* sums, long long count, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float momentum, float eps, int training, float* scale, float* shift,
+                   float* save_mean, float* save_rstd, int C, void* stream);
+int sv_scale_shift_act(const float* x, int ldx, const float* scale, const float* shift, const float* residual, int ldr,
+                       float* y, int ldy, long long M, int C, int act, float slope, void* stream);
+int sv_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const float* x, int ldx, const float* gamma,
+              const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
+              float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta, float* sums_ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention cores.  Window attention = timm WindowAttention + SwinTransformerBlock roll/partition/mask
+ * (call site models/swin_transformer.py:78): qkv [I*H*W, 3C] rows in natural (h,w) order, columns
+ * [q|k|v][head][32]; table [169, heads]; out [I*H*W, C].  Cross-view attention = models/
+ * cross_view_attention.py:78-105: qkv [B*V*P, 3R] channels-last rows (view image, position), scores over
+ * the V views of one sample scaled by 1/sqrt(head_dim*V).
+ * ---------------------------------------------------------------------------------------------- */
+int sv_window_attention_fwd(const float* qkv, const float* table, float* out, int I, int H, int W, int C, int heads,
+                            int shift, int math, void* stream);
+int sv_window_attention_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable,
+                            int I, int H, int W, int C, int heads, int shift, void* stream);
+int sv_cross_view_attention_fwd(const float* qkv, float* out, int B, int V, int P, int R, int heads, void* stream);
+int sv_cross_view_attention_bwd(const float* qkv, const float* dout, float* dqkv, int B, int V, int P, int R, int heads,
+                                void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layout / pooling / tail kernels (reference sites in the comments of csrc/elementwise.hip)
+ * ---------------------------------------------------------------------------------------------- */
+int sv_transpose(const float* src, float* dst, int batch, int R, int C, int lds, int ldd, long long src_bstride,
+                 long long dst_bstride, void* stream);                       /* dst[b][c][r] = src[b][r][c] */
+int sv_add_n(const float* a, const float* b, const float* c, const float* d, float* out, long long M, int C, int ldo, void* stream);
+int sv_axpby(const float* a, const float* b, float* out, float alpha, float beta, long long n, void* stream);
+int sv_relu_bwd(const float* dy, const float* y, float* out, long long n, void* stream);               /* refiner.py:51 (ReLU after layer5) */
+int sv_maxpool2d_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);   /* 3x3 s2 p1, encoder.py:23 (resnet maxpool) */
+int sv_maxpool2d_bwd(const float* dy, const uint8_t* idx, float* dx_zeroed, int N, int H, int W, int C, void* stream);
+int sv_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int ldy, int col_off, void* stream); /* encoder.py:123 */
+int sv_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, int ldy, int col_off, void* stream);
+int sv_decoder_seed_fwd(const float* feat, float* out, int I, int C, void* stream);                      /* decoder.py:59-67 */
+int sv_decoder_seed_bwd(const float* dout, float* dfeat, int I, int C, void* stream);
+int sv_maxpool3d_fwd(const float* x, float* y, uint8_t* idx, int N, int D, int H, int W, int C, void* stream); /* refiner.py:25,31,37 */
+int sv_maxpool3d_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int D, int H, int W, int C, void* stream);
+int sv_dropout(const float* x, float* y, long long n, float p, uint32_t seed, void* stream);            /* cross_view_attention.py:57,131 */
+int sv_droppath_scale(float* scale, int I, float p, uint32_t seed, void* stream);                        /* timm DropPath */
+int sv_rowscale(const float* x, const float* scale, float* y, long long rows, int C, int rows_per_scale, void* stream);
+int sv_dwconv2x2_fwd(const float* x, const float* w, const float* b, float* y, int I, int C, void* stream); /* cross_view_attention.py:26-32,68 */
+int sv_dwconv2x2_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int I, int C, void* stream);
+int sv_upsample3to7_add_fwd(const float* small, const float* x, int ldx, float* y, int I, int C, void* stream); /* cross_view_attention.py:110-120 */
+int sv_upsample3to7_bwd(const float* dy, float* dsmall, int I, int C, void* stream);
+int sv_decoder_head_fwd(const float* x8, const float* w, const float* bias, float* raw12, float* vol, long long M, void* stream); /* decoder.py:83-94 */
+int sv_decoder_head_bwd(const float* draw12, const float* dvol, const float* x8, const float* w, float* dx8, float* dw, float* dbias,
+                        long long M, void* stream);
+int sv_merge_views_fwd(const float* wlogit, const float* vol, float* out, int B, int V, int S, void* stream);  /* merger.py:91-104 */
+int sv_merge_views_bwd(const float* wlogit, const float* vol, const float* out, const float* dout, float* dwlogit, float* dvol,
+                       int B, int V, int S, void* stream);
+int sv_mean_views(const float* vol, float* out, int B, int V, int S, void* stream);                      /* core/train.py:246 */
+int sv_bce_logits(const float* x, const float* t, long long n, float* loss_accum, float* dx, const float* gscale_dev, void* stream); /* core/train.py:165,249,255 */
+int sv_iou_counts(const float* logits, const float* gt, const float* thresholds_dev, int nth, int B, int S, float* counts, void* stream); /* core/test.py:141-153 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWINVOX_HIP_H */

@@ -1,0 +1,596 @@
+// Attention kernels.
+//  * Swin window / shifted-window attention core (timm WindowAttention behind models/swin_transformer.py:78):
+//    one wave per (image, window, head); the cyclic shift, the 7x7 window partition/reverse and the 9-region
+//    shift mask are folded into the token index math (no materialised roll); q/k/v tiles of the window are
+//    staged in LDS, QK^T and PV run on MFMA, the softmax runs on the accumulator layout with 16-lane shuffles.
+//  * Cross-view attention core (models/cross_view_attention.py:81-105): one workgroup per (sample, head),
+//    V x V scores over 288-long features -- tiny, plain FMA.
+#include "common.h"
+
+namespace sv {
+
+constexpr int WT = 49;       // tokens per window
+constexpr int HD = 32;       // head dim (Swin-T/B: always 32)
+constexpr int LDQ_F = 36;    // fp32 row stride of q/k/v tiles
+constexpr int LDP_F = 68;    // fp32 row stride of the P tile
+constexpr int LDQ_H = 40;    // bf16 row stride of q/k tiles
+constexpr int LDP_H = 72;    // bf16 row stride of P and V^T tiles
+
+struct WinArgs {
+  const float* qkv; const float* table; float* out;   // fwd
+  const float* dout; float* dqkv; float* dtable;      // bwd
+  int I, H, W, C, heads, shift; float scale; int ntasks; int tasks_per_wave;
+};
+
+struct TokMap {  // window -> token rows of the un-shifted [I,H,W] map
+  int img, wy, wx, H, W, shift;
+  __device__ __forceinline__ long long row(int t) const {
+    const int ty = t / 7, tx = t - ty * 7;
+    int ys = wy * 7 + ty + shift; if (ys >= H) ys -= H;
+    int xs = wx * 7 + tx + shift; if (xs >= W) xs -= W;
+    return ((long long)img * H + ys) * W + xs;
+  }
+  __device__ __forceinline__ int region(int t) const {  // 9-region id in the rolled frame
+    const int ty = t / 7, tx = t - ty * 7;
+    const int ry = wy * 7 + ty, rx = wx * 7 + tx;
+    const int a = ry < H - 7 ? 0 : (ry < H - shift ? 1 : 2);
+    const int b = rx < W - 7 ? 0 : (rx < W - shift ? 1 : 2);
+    return a * 3 + b;
+  }
+};
+
+__device__ __forceinline__ float group16_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
+  v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+  return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// scores (+bias, +mask, key padding) -> softmax, all on the 4x4 grid of 16x16 accumulator tiles of one wave.
+// element (q = mt*16 + lg*4 + j, key = nt*16 + lr)
+__device__ __forceinline__ void bias_mask_softmax(f32x4 (&s)[4][4], const float* bt, const TokMap& tm, int lane, bool shifted) {
+  const int lr = lane & 15, lg = lane >> 4;
+  int ky[4], kx[4], kreg[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int key = nt * 16 + lr;
+    ky[nt] = key / 7; kx[nt] = key - ky[nt] * 7;
+    kreg[nt] = (shifted && key < WT) ? tm.region(key) : 0;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = mt * 16 + lg * 4 + j;
+      const int qy = q / 7, qx = q - qy * 7;
+      const int qreg = (shifted && q < WT) ? tm.region(q) : 0;
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int key = nt * 16 + lr;
+        float v = s[mt][nt][j];
+        if (key >= WT) v = -1.0e30f;
+        else if (q < WT) {
+          v += bt[(qy - ky[nt] + 6) * 13 + (qx - kx[nt] + 6)];
+          if (shifted && qreg != kreg[nt]) v += -100.0f;
+        }
+        s[mt][nt][j] = v;
+        mx = fmaxf(mx, v);
+      }
+      mx = group16_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) { const float e = __expf(s[mt][nt][j] - mx); s[mt][nt][j] = e; sum += e; }
+      const float inv = 1.f / group16_sum(sum);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) s[mt][nt][j] *= inv;
+    }
+}
+
+// load one [49(64) x 32] head slice of q, k or v (or dO) into an fp32 LDS tile, rows >= 49 zeroed
+__device__ __forceinline__ void load_tile_f32(float* dst, const float* src, int ld, int col, const TokMap& tm, int lane, float mul) {
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = (lane >> 3) + 8 * it, ch = (lane & 7) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < WT) {
+      v = *reinterpret_cast<const float4*>(src + (size_t)tm.row(r) * ld + col + ch);
+      v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+    }
+    *reinterpret_cast<float4*>(dst + r * LDQ_F + ch) = v;
+  }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void win_attn_fwd_kernel(const WinArgs p) {
+  constexpr int WAVE_BYTES = BF16 ? (2 * 64 * LDQ_H + HD * LDP_H) * 2 + 176 * 4 : 3 * 64 * LDQ_F * 4 + 176 * 4;
+  __shared__ __attribute__((aligned(16))) char smem[4 * WAVE_BYTES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int head = blockIdx.y;
+  const int nWx = p.W / 7, nW = (p.H / 7) * nWx;
+  long long task = (long long)blockIdx.x * 4 + wave;
+  const bool active = task < p.ntasks;
+  if (!active) task = p.ntasks - 1;
+  TokMap tm;
+  tm.img = (int)(task / nW); const int win = (int)(task - (long long)tm.img * nW);
+  tm.wy = win / nWx; tm.wx = win - tm.wy * nWx; tm.H = p.H; tm.W = p.W; tm.shift = p.shift;
+  const int ld = 3 * p.C, colq = head * HD;
+  char* base = smem + wave * WAVE_BYTES;
+  float* bt = reinterpret_cast<float*>(base + WAVE_BYTES - 176 * 4);
+  for (int i = lane; i < 169; i += 64) bt[i] = p.table[i * p.heads + head];
+
+  f32x4 s[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) s[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 o[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) { o[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; o[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  if constexpr (!BF16) {
+    float* Qs = reinterpret_cast<float*>(base);
+    float* Ks = Qs + 64 * LDQ_F;
+    float* Vs = Ks + 64 * LDQ_F;
+    float* Ps = Qs;  // aliases Q,K once the scores are in registers
+    load_tile_f32(Qs, p.qkv, ld, colq, tm, lane, p.scale);
+    load_tile_f32(Ks, p.qkv, ld, p.C + colq, tm, lane, 1.f);
+    load_tile_f32(Vs, p.qkv, ld, 2 * p.C + colq, tm, lane, 1.f);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < HD / 4; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { a[t] = Qs[(t * 16 + lr) * LDQ_F + kk * 4 + lg]; b[t] = Ks[(t * 16 + lr) * LDQ_F + kk * 4 + lg]; }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) s[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], s[mt][nt], 0, 0, 0);
+    }
+    bias_mask_softmax(s, bt, tm, lane, p.shift > 0);
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Ps[(mt * 16 + lg * 4 + j) * LDP_F + nt * 16 + lr] = s[mt][nt][j];
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[2];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) a[mt] = Ps[(mt * 16 + lr) * LDP_F + kk * 4 + lg];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) b[nt] = Vs[(kk * 4 + lg) * LDQ_F + nt * 16 + lr];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) o[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], o[mt][nt], 0, 0, 0);
+    }
+  } else {
+    __bf16* Qs = reinterpret_cast<__bf16*>(base);
+    __bf16* Ks = Qs + 64 * LDQ_H;
+    __bf16* Vt = Ks + 64 * LDQ_H;   // [d][key]
+    __bf16* Ps = Qs;                // [q][key], aliases Q,K
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = (lane >> 3) + 8 * it, ch = (lane & 7) * 4;
+      float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;
+      if (r < WT) {
+        const float* src = p.qkv + (size_t)tm.row(r) * ld + colq + ch;
+        q4 = *reinterpret_cast<const float4*>(src);
+        k4 = *reinterpret_cast<const float4*>(src + p.C);
+        v4 = *reinterpret_cast<const float4*>(src + 2 * p.C);
+      }
+      bf16x4 qb, kb;
+      qb[0] = (__bf16)(q4.x * p.scale); qb[1] = (__bf16)(q4.y * p.scale); qb[2] = (__bf16)(q4.z * p.scale); qb[3] = (__bf16)(q4.w * p.scale);
+      kb[0] = (__bf16)k4.x; kb[1] = (__bf16)k4.y; kb[2] = (__bf16)k4.z; kb[3] = (__bf16)k4.w;
+      *reinterpret_cast<bf16x4*>(Qs + r * LDQ_H + ch) = qb;
+      *reinterpret_cast<bf16x4*>(Ks + r * LDQ_H + ch) = kb;
+      Vt[(ch + 0) * LDP_H + r] = (__bf16)v4.x; Vt[(ch + 1) * LDP_H + r] = (__bf16)v4.y;
+      Vt[(ch + 2) * LDP_H + r] = (__bf16)v4.z; Vt[(ch + 3) * LDP_H + r] = (__bf16)v4.w;
+    }
+    __syncthreads();
+    {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = *reinterpret_cast<const bf16x8*>(Qs + (t * 16 + lr) * LDQ_H + lg * 8);
+        b[t] = *reinterpret_cast<const bf16x8*>(Ks + (t * 16 + lr) * LDQ_H + lg * 8);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) s[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], s[mt][nt], 0, 0, 0);
+    }
+    bias_mask_softmax(s, bt, tm, lane, p.shift > 0);
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Ps[(mt * 16 + lg * 4 + j) * LDP_H + nt * 16 + lr] = (__bf16)s[mt][nt][j];
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[2];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(Ps + (mt * 16 + lr) * LDP_H + ks * 32 + lg * 8);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(Vt + (nt * 16 + lr) * LDP_H + ks * 32 + lg * 8);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) o[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], o[mt][nt], 0, 0, 0);
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = mt * 16 + lg * 4 + j;
+        if (q < WT) {
+          float* dst = p.out + (size_t)tm.row(q) * p.C + colq;
+          dst[lr] = o[mt][0][j];
+          dst[16 + lr] = o[mt][1][j];
+        }
+      }
+  }
+}
+
+// backward (exact fp32 MFMA): recompute P, then dV = P^T dO, dP = dO V^T, dS = P o (dP - rowsum(dP o P)),
+// dQ = scale * dS K, dK = dS^T (scale*Q), dtable[idx] += dS.  Two waves per workgroup; a wave walks
+// tasks_per_wave windows of ONE head so its relative-position-bias gradient is reduced in LDS first.
+constexpr int BWD_WAVE_FLOATS = 4 * 64 * LDQ_F + 64 * LDP_F + 176 + 176;
+
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void win_attn_bwd_kernel(const WinArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * BWD_WAVE_FLOATS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int head = blockIdx.y;
+  const int nWx = p.W / 7, nW = (p.H / 7) * nWx;
+  float* Qs = smem + wave * BWD_WAVE_FLOATS;
+  float* Ks = Qs + 64 * LDQ_F;
+  float* Vs = Ks + 64 * LDQ_F;
+  float* Ds = Vs + 64 * LDQ_F;
+  float* PS = Ds + 64 * LDQ_F;
+  float* bt = PS + 64 * LDP_F;
+  float* dbt = bt + 176;
+  for (int i = lane; i < 176; i += 64) { bt[i] = i < 169 ? p.table[i * p.heads + head] : 0.f; dbt[i] = 0.f; }
+  const int ld = 3 * p.C, colq = head * HD;
+  const long long task0 = ((long long)blockIdx.x * 2 + wave) * p.tasks_per_wave;
+
+  for (int tt = 0; tt < p.tasks_per_wave; ++tt) {
+    long long task = task0 + tt;
+    const bool active = task < p.ntasks;   // inactive waves keep running (barriers) on a clamped task, stores suppressed
+    if (!active) task = p.ntasks - 1;
+    TokMap tm;
+    tm.img = (int)(task / nW); const int win = (int)(task - (long long)tm.img * nW);
+    tm.wy = win / nWx; tm.wx = win - tm.wy * nWx; tm.H = p.H; tm.W = p.W; tm.shift = p.shift;
+
+    __syncthreads();  // previous task's LDS reads done
+    load_tile_f32(Qs, p.qkv, ld, colq, tm, lane, p.scale);
+    load_tile_f32(Ks, p.qkv, ld, p.C + colq, tm, lane, 1.f);
+    load_tile_f32(Vs, p.qkv, ld, 2 * p.C + colq, tm, lane, 1.f);
+    load_tile_f32(Ds, p.dout, p.C, colq, tm, lane, 1.f);
+    __syncthreads();
+
+    f32x4 s[4][4], dp[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) { s[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int kk = 0; kk < HD / 4; ++kk) {
+      float a[4], b[4], c[4], d[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int off = (t * 16 + lr) * LDQ_F + kk * 4 + lg;
+        a[t] = Qs[off]; b[t] = Ks[off]; c[t] = Ds[off]; d[t] = Vs[off];
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          s[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], s[mt][nt], 0, 0, 0);
+          dp[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(c[mt], d[nt], dp[mt][nt], 0, 0, 0);
+        }
+    }
+    bias_mask_softmax(s, bt, tm, lane, p.shift > 0);
+    // dS = P o (dP - rowsum(dP o P)); kept in dp
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float r = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) r += dp[mt][nt][j] * s[mt][nt][j];
+        r = group16_sum(r);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) dp[mt][nt][j] = s[mt][nt][j] * (dp[mt][nt][j] - r);
+      }
+    // relative-position-bias gradient into the wave's LDS table
+    if (active) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = mt * 16 + lg * 4 + j;
+          if (q < WT) {
+            const int qy = q / 7, qx = q - qy * 7;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              const int key = nt * 16 + lr;
+              if (key < WT) {
+                const int ky = key / 7, kx = key - ky * 7;
+                atomicAdd(dbt + (qy - ky + 6) * 13 + (qx - kx + 6), dp[mt][nt][j]);
+              }
+            }
+          }
+        }
+    }
+    // ---- dV = P^T dO
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) PS[(mt * 16 + lg * 4 + j) * LDP_F + nt * 16 + lr] = s[mt][nt][j];
+    __syncthreads();
+    {
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 4
+      for (int kk = 0; kk < 16; ++kk) {
+        float a[4], b[2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a[mt] = PS[(kk * 4 + lg) * LDP_F + mt * 16 + lr];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b[nt] = Ds[(kk * 4 + lg) * LDQ_F + nt * 16 + lr];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      }
+      if (active) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int key = mt * 16 + lg * 4 + j;
+            if (key < WT) {
+              float* dst = p.dqkv + (size_t)tm.row(key) * ld + 2 * p.C + colq;
+              dst[lr] = acc[mt][0][j]; dst[16 + lr] = acc[mt][1][j];
+            }
+          }
+      }
+    }
+    __syncthreads();
+    // ---- dQ = scale * dS K ; dK = dS^T (scale*Q)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) PS[(mt * 16 + lg * 4 + j) * LDP_F + nt * 16 + lr] = dp[mt][nt][j];
+    __syncthreads();
+    {
+      f32x4 aq[4][2], ak[4][2];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        aq[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; aq[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ak[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; ak[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll 4
+      for (int kk = 0; kk < 16; ++kk) {
+        float a1[4], a2[4], b1[2], b2[2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          a1[mt] = PS[(mt * 16 + lr) * LDP_F + kk * 4 + lg];   // dS[q][key]
+          a2[mt] = PS[(kk * 4 + lg) * LDP_F + mt * 16 + lr];   // dS^T[key][q]
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          b1[nt] = Ks[(kk * 4 + lg) * LDQ_F + nt * 16 + lr];
+          b2[nt] = Qs[(kk * 4 + lg) * LDQ_F + nt * 16 + lr];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            aq[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mt], b1[nt], aq[mt][nt], 0, 0, 0);
+            ak[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[mt], b2[nt], ak[mt][nt], 0, 0, 0);
+          }
+      }
+      if (active) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int t = mt * 16 + lg * 4 + j;
+            if (t < WT) {
+              float* dst = p.dqkv + (size_t)tm.row(t) * ld + colq;
+              dst[lr] = aq[mt][0][j] * p.scale; dst[16 + lr] = aq[mt][1][j] * p.scale;
+              dst[p.C + lr] = ak[mt][0][j]; dst[p.C + 16 + lr] = ak[mt][1][j];
+            }
+          }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < 169; i += 64) {
+    const float v = dbt[i];
+    if (v != 0.f) atomicAdd(p.dtable + i * p.heads + head, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross-view attention core.  qkv: [B*V*P, 3R] channels-last rows (img, pos), R = heads*hd reduced channels;
+// feature of (view, head) = all (pos, c) with c in the head's hd channels -> F = P*hd (288).
+// ------------------------------------------------------------------------------------------------
+constexpr int CVA_MAXV = 32, CVA_MAXF = 288;
+
+struct CvaArgs { const float* qkv; float* out; const float* dout; float* dqkv; int B, V, P, R, heads, hd; float scale; };
+
+__device__ __forceinline__ size_t cva_off(const CvaArgs& p, int b, int v, int f, int head, int which, int ld) {
+  const int pos = f / p.hd, c = f - pos * p.hd;
+  return ((size_t)(b * p.V + v) * p.P + pos) * ld + which * p.R + head * p.hd + c;
+}
+
+__global__ __launch_bounds__(256) void cva_attn_fwd_kernel(const CvaArgs p) {
+  __shared__ float q[CVA_MAXV * CVA_MAXF], k[CVA_MAXV * CVA_MAXF], v[CVA_MAXV * CVA_MAXF];
+  __shared__ float a[CVA_MAXV * CVA_MAXV];
+  const int b = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+  const int F = p.P * p.hd, V = p.V;
+  for (int i = threadIdx.x; i < V * F; i += 256) {
+    const int vi = i / F, f = i - vi * F;
+    q[i] = p.qkv[cva_off(p, b, vi, f, head, 0, 3 * p.R)];
+    k[i] = p.qkv[cva_off(p, b, vi, f, head, 1, 3 * p.R)];
+    v[i] = p.qkv[cva_off(p, b, vi, f, head, 2, 3 * p.R)];
+  }
+  __syncthreads();
+  for (int ij = threadIdx.x; ij < V * V; ij += 256) {
+    const int i = ij / V, j = ij - i * V;
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += q[i * F + f] * k[j * F + f];
+    a[ij] = s * p.scale;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < V; i += 256) {
+    float mx = -3.0e38f;
+    for (int j = 0; j < V; ++j) mx = fmaxf(mx, a[i * V + j]);
+    float sum = 0.f;
+    for (int j = 0; j < V; ++j) { const float e = __expf(a[i * V + j] - mx); a[i * V + j] = e; sum += e; }
+    const float inv = 1.f / sum;
+    for (int j = 0; j < V; ++j) a[i * V + j] *= inv;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < V * F; i += 256) {
+    const int vi = i / F, f = i - vi * F;
+    float o = 0.f;
+    for (int j = 0; j < V; ++j) o += a[vi * V + j] * v[j * F + f];
+    p.out[cva_off(p, b, vi, f, head, 0, p.R)] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void cva_attn_bwd_kernel(const CvaArgs p) {
+  __shared__ float q[CVA_MAXV * CVA_MAXF], k[CVA_MAXV * CVA_MAXF], v[CVA_MAXV * CVA_MAXF], d[CVA_MAXV * CVA_MAXF];
+  __shared__ float a[CVA_MAXV * CVA_MAXV], ds[CVA_MAXV * CVA_MAXV];
+  const int b = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+  const int F = p.P * p.hd, V = p.V;
+  for (int i = threadIdx.x; i < V * F; i += 256) {
+    const int vi = i / F, f = i - vi * F;
+    q[i] = p.qkv[cva_off(p, b, vi, f, head, 0, 3 * p.R)];
+    k[i] = p.qkv[cva_off(p, b, vi, f, head, 1, 3 * p.R)];
+    v[i] = p.qkv[cva_off(p, b, vi, f, head, 2, 3 * p.R)];
+    d[i] = p.dout[cva_off(p, b, vi, f, head, 0, p.R)];
+  }
+  __syncthreads();
+  for (int ij = threadIdx.x; ij < V * V; ij += 256) {
+    const int i = ij / V, j = ij - i * V;
+    float s = 0.f, da = 0.f;
+    for (int f = 0; f < F; ++f) { s += q[i * F + f] * k[j * F + f]; da += d[i * F + f] * v[j * F + f]; }
+    a[ij] = s * p.scale; ds[ij] = da;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < V; i += 256) {
+    float mx = -3.0e38f;
+    for (int j = 0; j < V; ++j) mx = fmaxf(mx, a[i * V + j]);
+    float sum = 0.f;
+    for (int j = 0; j < V; ++j) { const float e = __expf(a[i * V + j] - mx); a[i * V + j] = e; sum += e; }
+    const float inv = 1.f / sum;
+    float r = 0.f;
+    for (int j = 0; j < V; ++j) { a[i * V + j] *= inv; r += a[i * V + j] * ds[i * V + j]; }
+    for (int j = 0; j < V; ++j) ds[i * V + j] = a[i * V + j] * (ds[i * V + j] - r) * p.scale;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < V * F; i += 256) {
+    const int vi = i / F, f = i - vi * F;
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int j = 0; j < V; ++j) {
+      dq += ds[vi * V + j] * k[j * F + f];
+      dk += ds[j * V + vi] * q[j * F + f];
+      dv += a[j * V + vi] * d[j * F + f];
+    }
+    p.dqkv[cva_off(p, b, vi, f, head, 0, 3 * p.R)] = dq;
+    p.dqkv[cva_off(p, b, vi, f, head, 1, 3 * p.R)] = dk;
+    p.dqkv[cva_off(p, b, vi, f, head, 2, 3 * p.R)] = dv;
+  }
+}
+
+}  // namespace sv
+
+using namespace sv;
+
+static int win_check(const float* qkv, const float* table, int I, int H, int W, int C, int heads, int shift) {
+  SV_REQUIRE(qkv && table && I > 0, "window_attention: null/empty argument");
+  SV_REQUIRE(H % 7 == 0 && W % 7 == 0 && H >= 7 && W >= 7, "window_attention: map %dx%d is not a multiple of the 7x7 window", H, W);
+  SV_REQUIRE(C == heads * HD, "window_attention: C (%d) must equal heads (%d) * 32", C, heads);
+  SV_REQUIRE(shift >= 0 && shift < 7 && (shift == 0 || (H > 7 && W > 7)), "window_attention: bad shift %d for map %dx%d", shift, H, W);
+  SV_REQUIRE(((uintptr_t)qkv & 15) == 0, "window_attention: qkv must be 16-byte aligned");
+  return SV_OK;
+}
+
+extern "C" int sv_window_attention_fwd(const float* qkv, const float* table, float* out, int I, int H, int W, int C, int heads,
+                                       int shift, int math, void* stream) {
+  if (int rc = win_check(qkv, table, I, H, W, C, heads, shift)) return rc;
+  SV_REQUIRE(out, "window_attention_fwd: null out");
+  WinArgs a{};
+  a.qkv = qkv; a.table = table; a.out = out; a.I = I; a.H = H; a.W = W; a.C = C; a.heads = heads; a.shift = shift;
+  a.scale = 1.0f / sqrtf((float)HD);
+  a.ntasks = I * (H / 7) * (W / 7);
+  dim3 grid(cdiv(a.ntasks, 4), heads);
+  if (math == SV_MATH_BF16) hipLaunchKernelGGL((win_attn_fwd_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((win_attn_fwd_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("sv_window_attention_fwd");
+}
+
+extern "C" int sv_window_attention_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable,
+                                       int I, int H, int W, int C, int heads, int shift, void* stream) {
+  if (int rc = win_check(qkv, table, I, H, W, C, heads, shift)) return rc;
+  SV_REQUIRE(dout && dqkv && dtable && ((uintptr_t)dout & 15) == 0, "window_attention_bwd: null/unaligned argument");
+  WinArgs a{};
+  a.qkv = qkv; a.table = table; a.dout = dout; a.dqkv = dqkv; a.dtable = dtable;
+  a.I = I; a.H = H; a.W = W; a.C = C; a.heads = heads; a.shift = shift;
+  a.scale = 1.0f / sqrtf((float)HD);
+  a.ntasks = I * (H / 7) * (W / 7);
+  // several windows per wave (same head) so the bias gradient is reduced on chip; keep >= ~1024 waves in the grid
+  int tpw = 1;
+  while (tpw < 8 && (long long)a.ntasks * heads / (tpw * 2) > 2048) tpw *= 2;
+  a.tasks_per_wave = tpw;
+  dim3 grid(cdiv(a.ntasks, 2 * tpw), heads);
+  hipLaunchKernelGGL(win_attn_bwd_kernel, grid, dim3(128), 0, (hipStream_t)stream, a);
+  return check_launch("sv_window_attention_bwd");
+}
+
+static int cva_check(int B, int V, int P, int R, int heads) {
+  SV_REQUIRE(B > 0 && V > 0 && V <= CVA_MAXV, "cross_view_attention: n_views=%d unsupported (max %d)", V, CVA_MAXV);
+  SV_REQUIRE(heads > 0 && R % heads == 0 && P * (R / heads) <= CVA_MAXF, "cross_view_attention: feature length %d exceeds %d",
+             P * (R / (heads > 0 ? heads : 1)), CVA_MAXF);
+  return SV_OK;
+}
+
+extern "C" int sv_cross_view_attention_fwd(const float* qkv, float* out, int B, int V, int P, int R, int heads, void* stream) {
+  SV_REQUIRE(qkv && out, "cross_view_attention_fwd: null argument");
+  if (int rc = cva_check(B, V, P, R, heads)) return rc;
+  CvaArgs a{qkv, out, nullptr, nullptr, B, V, P, R, heads, R / heads, 1.0f / sqrtf((float)(R / heads) * (float)V)};
+  hipLaunchKernelGGL(cva_attn_fwd_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("sv_cross_view_attention_fwd");
+}
+
+extern "C" int sv_cross_view_attention_bwd(const float* qkv, const float* dout, float* dqkv, int B, int V, int P, int R, int heads,
+                                           void* stream) {
+  SV_REQUIRE(qkv && dout && dqkv, "cross_view_attention_bwd: null argument");
+  if (int rc = cva_check(B, V, P, R, heads)) return rc;
+  CvaArgs a{qkv, nullptr, dout, dqkv, B, V, P, R, heads, R / heads, 1.0f / sqrtf((float)(R / heads) * (float)V)};
+  hipLaunchKernelGGL(cva_attn_bwd_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("sv_cross_view_attention_bwd");
+}

@@ -1,0 +1,526 @@
+// Normalisation kernels (HBM-bound): token LayerNorm (+ fused PatchMerging gather), whole-image
+// LayerNorm([C,H,W]) of the Swin stage heads, BatchNorm statistics / apply / backward on channels-last data.
+#include "common.h"
+
+namespace sv {
+
+// ------------------------------------------------------------------------------------------------
+// token LayerNorm: one wave per row, row kept in registers (C <= 3072), two-pass variance.
+// MERGE: the row is the PatchMerging gather of 4 tokens (order h0w0,h1w0,h0w1,h1w1) of a [I,H,W,C0] map.
+// ------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 12;  // float4 chunks per lane -> C <= 64*4*12 = 3072
+
+struct MergeMap { int H, W, C0; };  // H,W of the un-merged map
+
+template <bool MERGE>
+__device__ __forceinline__ size_t ln_src_off(long long row, int chunk, int C, const MergeMap& mm) {
+  if constexpr (!MERGE) return (size_t)row * C + chunk * 4;
+  const int e = chunk * 4;
+  const int blk = e / mm.C0, c = e - blk * mm.C0;   // blk = wp*2 + hp
+  const int wp = blk >> 1, hp = blk & 1;
+  const int W2 = mm.W >> 1, H2 = mm.H >> 1;
+  const int x2 = (int)(row % W2); long long t = row / W2;
+  const int y2 = (int)(t % H2); const long long i = t / H2;
+  return ((size_t)(i * mm.H + 2 * y2 + hp) * mm.W + (2 * x2 + wp)) * mm.C0 + c;
+}
+
+template <bool MERGE>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     long long rows, int C, float eps, MergeMap mm) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = C >> 2;
+  float4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunk) {
+      v[i] = *reinterpret_cast<const float4*>(x + ln_src_off<MERGE>(row, ch, C, mm));
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunk) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + b * b + c * c + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunk) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + ch * 4);
+      const float4 b = *reinterpret_cast<const float4*>(beta + ch * 4);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      *reinterpret_cast<float4*>(y + (size_t)row * C + ch * 4) = o;
+    }
+  }
+}
+
+// backward: dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma; dgamma += dy*xhat, dbeta += dy.
+// A workgroup walks ROWS_PER_BLOCK rows (each wave a strided subset) so that the per-column partial sums
+// stay in registers and only one atomic per column per workgroup reaches HBM.
+constexpr int LN_BWD_ROWS = 64;
+
+template <bool MERGE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, float* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     long long rows, int C, MergeMap mm, int accumulate_dx) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2*C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = C >> 2;
+  float4 dg[LN_MAXV], db[LN_MAXV], gm[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    dg[i] = make_float4(0, 0, 0, 0); db[i] = make_float4(0, 0, 0, 0);
+    const int ch = lane + 64 * i;
+    gm[i] = ch < nchunk ? *reinterpret_cast<const float4*>(gamma + ch * 4) : make_float4(0, 0, 0, 0);
+  }
+  const long long r0 = (long long)blockIdx.x * LN_BWD_ROWS;
+  for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
+    const long long row = r0 + rr;
+    if (row >= rows) break;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float4 xh[LN_MAXV], g[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nchunk) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + ln_src_off<MERGE>(row, ch, C, mm));
+        const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)row * C + ch * 4);
+        xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd; xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
+        g[i].x = d.x * gm[i].x; g[i].y = d.y * gm[i].y; g[i].z = d.z * gm[i].z; g[i].w = d.w * gm[i].w;
+        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+        dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
+        db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+      }
+    }
+    const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nchunk) {
+        float4 o;
+        o.x = rstd * (g[i].x - m1 - xh[i].x * m2); o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
+        o.z = rstd * (g[i].z - m1 - xh[i].z * m2); o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
+        float* dst = dx + ln_src_off<MERGE>(row, ch, C, mm);
+        if (accumulate_dx) {
+          const float4 old = *reinterpret_cast<const float4*>(dst);
+          o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *reinterpret_cast<float4*>(dst) = o;
+      }
+    }
+  }
+  // fold the 4 waves' column partials through one LDS image (wave by wave), then one atomic per column
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nchunk) {
+          float4 a = dg[i], b = db[i];
+          if (w > 0) {
+            const float4 oa = *reinterpret_cast<const float4*>(red + ch * 4), ob = *reinterpret_cast<const float4*>(red + C + ch * 4);
+            a.x += oa.x; a.y += oa.y; a.z += oa.z; a.w += oa.w;
+            b.x += ob.x; b.y += ob.y; b.z += ob.z; b.w += ob.w;
+          }
+          *reinterpret_cast<float4*>(red + ch * 4) = a;
+          *reinterpret_cast<float4*>(red + C + ch * 4) = b;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    if (c < C) atomicAdd(dgamma + c, red[c]); else atomicAdd(dbeta + c - C, red[c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// long-row LayerNorm with a full-size affine (Swin stage heads: nn.LayerNorm([C,H,W]) on NHWC data whose
+// affine parameters were transposed to [HW,C] once per step).  L = H*W*C up to 301,056 per image.
+// Pass 1: every workgroup reduces a CHUNK of one image to (mean_chunk, M2_chunk); pass 2 merges the
+// chunk moments (Chan) and applies the affine (+ optional dropout mask).
+// ------------------------------------------------------------------------------------------------
+constexpr int LNL_CHUNK = 4096;  // elements per workgroup in pass 1 (16 per thread)
+
+__global__ __launch_bounds__(256) void lnl_moments_kernel(const float* __restrict__ x, float* __restrict__ part, int L, int nchunks) {
+  __shared__ float sc[4];
+  const int img = blockIdx.y, ck = blockIdx.x;
+  const int e0 = ck * LNL_CHUNK;
+  int n = L - e0; if (n > LNL_CHUNK) n = LNL_CHUNK;
+  const float* src = x + (size_t)img * L + e0;
+  float4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = (threadIdx.x + 256 * i) * 4;
+    if (e < n) { v[i] = *reinterpret_cast<const float4*>(src + e); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+  }
+  const float mean = block_sum<4>(s, sc) / n;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = (threadIdx.x + 256 * i) * 4;
+    if (e < n) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + b * b + c * c + d * d;
+    }
+  }
+  const float m2 = block_sum<4>(q, sc);
+  if (threadIdx.x == 0) {
+    part[((size_t)img * nchunks + ck) * 2 + 0] = mean;
+    part[((size_t)img * nchunks + ck) * 2 + 1] = m2;
+  }
+}
+
+__global__ void lnl_finalize_kernel(const float* __restrict__ part, float* __restrict__ meanrstd, int L, int nchunks, float eps, int I) {
+  const int img = blockIdx.x * blockDim.x + threadIdx.x;
+  if (img >= I) return;
+  float n_a = 0.f, mean_a = 0.f, m2_a = 0.f;
+  for (int c = 0; c < nchunks; ++c) {
+    int nb = L - c * LNL_CHUNK; if (nb > LNL_CHUNK) nb = LNL_CHUNK;
+    const float mean_b = part[((size_t)img * nchunks + c) * 2], m2_b = part[((size_t)img * nchunks + c) * 2 + 1];
+    const float n = n_a + nb, delta = mean_b - mean_a;
+    mean_a += delta * nb / n;
+    m2_a += m2_b + delta * delta * n_a * nb / n;
+    n_a = n;
+  }
+  meanrstd[img * 2] = mean_a;
+  meanrstd[img * 2 + 1] = rsqrtf(m2_a / L + eps);
+}
+
+__global__ __launch_bounds__(256) void lnl_apply_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, const float* __restrict__ meanrstd,
+                                                        float* __restrict__ y, int L, float drop_p, uint32_t seed) {
+  const int img = blockIdx.y;
+  const float mean = meanrstd[img * 2], rstd = meanrstd[img * 2 + 1];
+  const float keep_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (int e = (blockIdx.x * 256 + threadIdx.x) * 4; e < L; e += gridDim.x * 1024) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)img * L + e);
+    const float4 wv = *reinterpret_cast<const float4*>(w + e), bv = *reinterpret_cast<const float4*>(b + e);
+    float o[4] = {(xv.x - mean) * rstd * wv.x + bv.x, (xv.y - mean) * rstd * wv.y + bv.y,
+                  (xv.z - mean) * rstd * wv.z + bv.z, (xv.w - mean) * rstd * wv.w + bv.w};
+    if (drop_p > 0.f) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = uniform01(seed, (uint64_t)img * L + e + j) < drop_p ? 0.f : o[j] * keep_inv;
+    }
+    *reinterpret_cast<float4*>(y + (size_t)img * L + e) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// backward pass 1: per-image sums of g and g*xhat (g = dy*mask*w) -> sums[I][2] (atomics)
+__global__ __launch_bounds__(256) void lnl_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ w, const float* __restrict__ meanrstd,
+                                                             float* __restrict__ sums, int L, float drop_p, uint32_t seed) {
+  __shared__ float sc[4];
+  const int img = blockIdx.y;
+  const float mean = meanrstd[img * 2], rstd = meanrstd[img * 2 + 1];
+  const float keep_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int e = (blockIdx.x * 256 + threadIdx.x) * 4; e < L; e += gridDim.x * 1024) {
+    const float4 dv = *reinterpret_cast<const float4*>(dy + (size_t)img * L + e);
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)img * L + e);
+    const float4 wv = *reinterpret_cast<const float4*>(w + e);
+    const float d[4] = {dv.x, dv.y, dv.z, dv.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float dd = d[j];
+      if (drop_p > 0.f) dd = uniform01(seed, (uint64_t)img * L + e + j) < drop_p ? 0.f : dd * keep_inv;
+      const float g = dd * ww[j];
+      s1 += g; s2 += g * (xx[j] - mean) * rstd;
+    }
+  }
+  s1 = block_sum<4>(s1, sc);
+  s2 = block_sum<4>(s2, sc);
+  if (threadIdx.x == 0) { atomicAdd(sums + img * 2, s1); atomicAdd(sums + img * 2 + 1, s2); }
+}
+
+// backward pass 2: dx per element; dw/db accumulated over the images by the thread that owns element e
+__global__ __launch_bounds__(256) void lnl_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ w, const float* __restrict__ meanrstd,
+                                                            const float* __restrict__ sums, float* __restrict__ dx,
+                                                            float* __restrict__ dw, float* __restrict__ db, int L, int I,
+                                                            float drop_p, uint32_t seed) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= L) return;
+  const float keep_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const float wv = w[e];
+  float aw = 0.f, ab = 0.f;
+  for (int img = 0; img < I; ++img) {
+    const float mean = meanrstd[img * 2], rstd = meanrstd[img * 2 + 1];
+    float dd = dy[(size_t)img * L + e];
+    if (drop_p > 0.f) dd = uniform01(seed, (uint64_t)img * L + e) < drop_p ? 0.f : dd * keep_inv;
+    const float xh = (x[(size_t)img * L + e] - mean) * rstd;
+    const float g = dd * wv;
+    dx[(size_t)img * L + e] = rstd * (g - sums[img * 2] / L - xh * sums[img * 2 + 1] / L);
+    aw += dd * xh; ab += dd;
+  }
+  dw[e] += aw; db[e] += ab;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm on channels-last [M, C] (row stride ld)
+// ------------------------------------------------------------------------------------------------
+// per-channel sum and sum of squares (when the producing contraction did not accumulate them itself)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long long M, int C, int ld,
+                                                       float* __restrict__ sums, long long rows_per_block) {
+  __shared__ float r1[4][64], r2[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  long long r1e = r0 + rows_per_block; if (r1e > M) r1e = M;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) for (long long r = r0 + rl; r < r1e; r += 4) { const float v = x[(size_t)r * ld + c]; s1 += v; s2 += v * v; }
+  r1[rl][threadIdx.x & 63] = s1; r2[rl][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    atomicAdd(sums + c, r1[0][threadIdx.x] + r1[1][threadIdx.x] + r1[2][threadIdx.x] + r1[3][threadIdx.x]);
+    atomicAdd(sums + C + c, r2[0][threadIdx.x] + r2[1][threadIdx.x] + r2[2][threadIdx.x] + r2[3][threadIdx.x]);
+  }
+}
+
+// train: batch mean / biased var -> scale, shift, saved mean/rstd, running-stat update (unbiased var).
+// eval : scale/shift from the running statistics.
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float momentum, float eps, int training,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+                                   float* __restrict__ save_rstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    mean = sums[c] / count;
+    var = fmaxf(sums[C + c] / count - mean * mean, 0.f);
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count > 1.f ? count / (count - 1.f) : 1.f);
+  } else {
+    mean = running_mean[c]; var = running_var[c];
+  }
+  const float rstd = rsqrtf(var + eps);
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc; shift[c] = beta[c] - mean * sc;
+  save_mean[c] = mean; save_rstd[c] = rstd;
+}
+
+// y = act(x*scale[c] + shift[c] (+ residual))
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const float* __restrict__ res,
+                                                              int ldr, float* __restrict__ y, int ldy, long long M, int C,
+                                                              int act, float slope) {
+  const int cv = C >> 2;  // C % 4 == 0 path
+  const long long total = M * cv;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / cv; const int c = (int)(i - r * cv) * 4;
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+    float o[4] = {xv.x * sc.x + sh.x, xv.y * sc.y + sh.y, xv.z * sc.z + sh.z, xv.w * sc.w + sh.w};
+    if (res) {
+      const float4 rv = *reinterpret_cast<const float4*>(res + (size_t)r * ldr + c);
+      o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j], act, slope);
+    *reinterpret_cast<float4*>(y + (size_t)r * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+__global__ __launch_bounds__(256) void scale_shift_act_scalar_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, const float* __restrict__ res,
+                                                                     int ldr, float* __restrict__ y, int ldy, long long M, int C,
+                                                                     int act, float slope) {
+  const long long total = M * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C; const int c = (int)(i - r * C);
+    float o = x[(size_t)r * ldx + c] * scale[c] + shift[c];
+    if (res) o += res[(size_t)r * ldr + c];
+    y[(size_t)r * ldy + c] = apply_act(o, act, slope);
+  }
+}
+
+// backward pass 1: per channel s1 = sum(dz'), s2 = sum(dz' * xhat), dz' = dz * act'(z) (mask from the OUTPUT z)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz,
+                                                            const float* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, long long M, int C, int act, float slope,
+                                                            float* __restrict__ sums, long long rows_per_block) {
+  __shared__ float r1[4][64], r2[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  long long r1e = r0 + rows_per_block; if (r1e > M) r1e = M;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const float mu = mean[c], rs = rstd[c];
+    for (long long r = r0 + rl; r < r1e; r += 4) {
+      float d = dz[(size_t)r * lddz + c];
+      if (act != SV_ACT_NONE) d *= (z[(size_t)r * ldz + c] > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
+      s1 += d; s2 += d * (x[(size_t)r * ldx + c] - mu) * rs;
+    }
+  }
+  r1[rl][threadIdx.x & 63] = s1; r2[rl][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    atomicAdd(sums + c, r1[0][threadIdx.x] + r1[1][threadIdx.x] + r1[2][threadIdx.x] + r1[3][threadIdx.x]);
+    atomicAdd(sums + C + c, r2[0][threadIdx.x] + r2[1][threadIdx.x] + r2[2][threadIdx.x] + r2[3][threadIdx.x]);
+  }
+}
+
+// backward pass 2: dx = gamma*rstd*(dz' - s1/M - xhat*s2/M) (train) or dz'*gamma*rstd (eval); dres = dz' (optional);
+// block 0 also folds the sums into dgamma/dbeta
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz,
+                                                           const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ sums, long long M, int C, int act, float slope,
+                                                           int training, float* __restrict__ dx, int lddx, float* __restrict__ dres,
+                                                           int lddres, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const long long total = M * C;
+  const float invM = 1.f / (float)M;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C; const int c = (int)(i - r * C);
+    float d = dz[(size_t)r * lddz + c];
+    if (act != SV_ACT_NONE) d *= (z[(size_t)r * ldz + c] > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
+    if (dres) dres[(size_t)r * lddres + c] = d;
+    const float rs = rstd[c];
+    float o;
+    if (training) {
+      const float xh = (x[(size_t)r * ldx + c] - mean[c]) * rs;
+      o = gamma[c] * rs * (d - sums[c] * invM - xh * sums[C + c] * invM);
+    } else {
+      o = d * gamma[c] * rs;
+    }
+    dx[(size_t)r * lddx + c] = o;
+  }
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += 256) { dgamma[c] += sums[C + c]; dbeta[c] += sums[c]; }
+}
+
+}  // namespace sv
+
+using namespace sv;
+
+extern "C" int sv_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                long long rows, int C, float eps, int merge_H, int merge_W, void* stream) {
+  SV_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0, "layernorm_fwd: null/empty argument");
+  SV_REQUIRE(C % 4 == 0 && C <= 64 * 4 * LN_MAXV, "layernorm_fwd: C=%d must be a multiple of 4 and <= %d", C, 64 * 4 * LN_MAXV);
+  hipStream_t s = (hipStream_t)stream;
+  if (merge_H > 0) {
+    SV_REQUIRE(merge_H % 2 == 0 && merge_W % 2 == 0 && C % 16 == 0, "layernorm_fwd(merge): H,W must be even and C a multiple of 16");
+    MergeMap mm{merge_H, merge_W, C / 4};
+    hipLaunchKernelGGL((ln_fwd_kernel<true>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps, mm);
+  } else {
+    MergeMap mm{0, 0, 0};
+    hipLaunchKernelGGL((ln_fwd_kernel<false>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps, mm);
+  }
+  return check_launch("sv_layernorm_fwd");
+}
+
+extern "C" int sv_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                float* dx, float* dgamma, float* dbeta, long long rows, int C, int merge_H, int merge_W,
+                                int accumulate_dx, void* stream) {
+  SV_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "layernorm_bwd: null/empty argument");
+  SV_REQUIRE(C % 4 == 0 && C <= 64 * 4 * LN_MAXV, "layernorm_bwd: C=%d unsupported", C);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = sizeof(float) * 2 * C;
+  if (merge_H > 0) {
+    MergeMap mm{merge_H, merge_W, C / 4};
+    hipLaunchKernelGGL((ln_bwd_kernel<true>), dim3(cdiv(rows, LN_BWD_ROWS)), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx);
+  } else {
+    MergeMap mm{0, 0, 0};
+    hipLaunchKernelGGL((ln_bwd_kernel<false>), dim3(cdiv(rows, LN_BWD_ROWS)), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx);
+  }
+  return check_launch("sv_layernorm_bwd");
+}
+
+extern "C" size_t sv_ln_image_workspace_floats(int I, int L) { return (size_t)I * cdiv(L, LNL_CHUNK) * 2; }
+
+extern "C" int sv_ln_image_fwd(const float* x, const float* w, const float* b, float* y, float* meanrstd, float* workspace,
+                               int I, int L, float eps, float drop_p, uint32_t seed, void* stream) {
+  SV_REQUIRE(x && w && b && y && meanrstd && workspace && I > 0 && L > 0 && L % 4 == 0, "ln_image_fwd: bad arguments (I=%d L=%d)", I, L);
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = cdiv(L, LNL_CHUNK);
+  hipLaunchKernelGGL(lnl_moments_kernel, dim3(nch, I), dim3(256), 0, s, x, workspace, L, nch);
+  hipLaunchKernelGGL(lnl_finalize_kernel, dim3(cdiv(I, 64)), dim3(64), 0, s, workspace, meanrstd, L, nch, eps, I);
+  int gx = cdiv(L, 1024); if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(lnl_apply_kernel, dim3(gx, I), dim3(256), 0, s, x, w, b, meanrstd, y, L, drop_p, seed);
+  return check_launch("sv_ln_image_fwd");
+}
+
+extern "C" int sv_ln_image_bwd(const float* dy, const float* x, const float* w, const float* meanrstd, float* dx, float* dw,
+                               float* db, float* sums_ws, int I, int L, float drop_p, uint32_t seed, void* stream) {
+  SV_REQUIRE(dy && x && w && meanrstd && dx && dw && db && sums_ws && I > 0 && L > 0 && L % 4 == 0, "ln_image_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(sums_ws, 0, sizeof(float) * 2 * I, s);
+  int gx = cdiv(L, 1024); if (gx > 32) gx = 32;
+  hipLaunchKernelGGL(lnl_bwd_reduce_kernel, dim3(gx, I), dim3(256), 0, s, dy, x, w, meanrstd, sums_ws, L, drop_p, seed);
+  hipLaunchKernelGGL(lnl_bwd_apply_kernel, dim3(cdiv(L, 256)), dim3(256), 0, s, dy, x, w, meanrstd, sums_ws, dx, dw, db, L, I, drop_p, seed);
+  return check_launch("sv_ln_image_bwd");
+}
+
+extern "C" int sv_bn_stats(const float* x, long long M, int C, int ld, float* sums, void* stream) {
+  SV_REQUIRE(x && sums && M > 0 && C > 0 && ld >= C, "bn_stats: bad arguments");
+  const int cg = cdiv(C, 64);
+  long long splits = 2048 / cg; if (splits < 1) splits = 1;
+  const long long maxs = (M + 63) / 64; if (splits > maxs) splits = maxs;
+  const long long rpb = (M + splits - 1) / splits;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(cg, cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, x, M, C, ld, sums, rpb);
+  return check_launch("sv_bn_stats");
+}
+
+extern "C" int sv_bn_finalize(const float* sums, long long count, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float momentum, float eps, int training, float* scale, float* shift,
+                              float* save_mean, float* save_rstd, int C, void* stream) {
+  SV_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && save_mean && save_rstd && C > 0, "bn_finalize: null argument");
+  SV_REQUIRE(!training || (sums && count > 0), "bn_finalize: training needs sums and a positive count");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, (float)count, gamma, beta,
+                     running_mean, running_var, momentum, eps, training, scale, shift, save_mean, save_rstd, C);
+  return check_launch("sv_bn_finalize");
+}
+
+extern "C" int sv_scale_shift_act(const float* x, int ldx, const float* scale, const float* shift, const float* residual, int ldr,
+                                  float* y, int ldy, long long M, int C, int act, float slope, void* stream) {
+  SV_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && ldx >= C && ldy >= C, "scale_shift_act: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (!residual || ldr % 4 == 0) &&
+                   (((uintptr_t)x | (uintptr_t)y | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)residual) & 15) == 0;
+  if (vec) {
+    long long blocks = (M * (C / 4) + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scale_shift_act_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, scale, shift, residual, ldr, y, ldy, M, C, act, slope);
+  } else {
+    long long blocks = (M * C + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scale_shift_act_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, scale, shift, residual, ldr, y, ldy, M, C, act, slope);
+  }
+  return check_launch("sv_scale_shift_act");
+}
+
+extern "C" int sv_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const float* x, int ldx, const float* gamma,
+                         const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
+                         float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta, float* sums_ws, void* stream) {
+  SV_REQUIRE(dz && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && sums_ws && M > 0 && C > 0, "bn_bwd: null/empty argument");
+  SV_REQUIRE(act == SV_ACT_NONE || z, "bn_bwd: the activation mask needs the forward output z");
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(sums_ws, 0, sizeof(float) * 2 * C, s);
+  const int cg = cdiv(C, 64);
+  long long splits = 2048 / cg; if (splits < 1) splits = 1;
+  const long long maxs = (M + 63) / 64; if (splits > maxs) splits = maxs;
+  const long long rpb = (M + splits - 1) / splits;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz, lddz, z, ldz, x, ldx, save_mean, save_rstd, M, C, act, slope, sums_ws, rpb);
+  long long blocks = (M * C + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dz, lddz, z, ldz, x, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
+                     act, slope, training, dx, lddx, dres, lddres, dgamma, dbeta);
+  return check_launch("sv_bn_bwd");
+}

@@ -1,0 +1,133 @@
+"""ctypes binding of libswinvox_hip.so (include/swinvox_hip.h).
+
+The library is the product: there is NO eager/CPU fallback.  Importing this module never touches the
+GPU (forked DataLoader workers stay safe, reference core/train.py:64-76); the first call that needs the
+library raises RuntimeError if it was not built (python __graft_entry__.py build  /  make -C swinvox_amd/csrc).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswinvox_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_LRELU = 0, 1, 2, 3
+MATH_F32, MATH_BF16 = 0, 1
+
+
+class Geom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "Ci", "Co", "kd", "kh", "kw",
+                                        "sd", "sh", "sw", "pd", "ph", "pw", "ldi")]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int), ("row_scale", C.c_void_p),
+                ("rows_per_scale", C.c_int), ("pre_act", C.c_void_p), ("stats", C.c_void_p), ("act", C.c_int),
+                ("slope", C.c_float), ("act_grad_src", C.c_void_p), ("act_grad_kind", C.c_int), ("ldc", C.c_int),
+                ("col_off", C.c_int)]
+
+
+# name -> (restype, argtypes); p = device/host pointer, i = int, l = long long, f = float, u = uint32, z = size_t
+_P, _I, _L, _F, _U = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint32
+_PROTOS = {
+    "sv_version": (_I, []),
+    "sv_conv_gather": (_I, [_P, _P, _P, C.POINTER(Geom), C.POINTER(Epilogue), _I, _P]),
+    "sv_tconv_gather": (_I, [_P, _P, _P, C.POINTER(Geom), C.POINTER(Epilogue), _I, _P]),
+    "sv_conv_wgrad": (_I, [_P, _I, _P, _P, C.POINTER(Geom), _I, _I, _P]),
+    "sv_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "sv_colsum": (_I, [_P, _I, _I, _I, _P, _I, _P]),
+    "sv_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
+    "sv_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "sv_ln_image_workspace_floats": (C.c_size_t, [_I, _I]),
+    "sv_ln_image_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U, _P]),
+    "sv_ln_image_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P]),
+    "sv_bn_stats": (_I, [_P, _L, _I, _I, _P, _P]),
+    "sv_bn_finalize": (_I, [_P, _L, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _I, _P]),
+    "sv_scale_shift_act": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _F, _P]),
+    "sv_bn_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _L, _I, _I, _F, _I, _P, _I, _P, _I, _P, _P, _P, _P]),
+    "sv_window_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sv_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sv_cross_view_attention_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "sv_cross_view_attention_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sv_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _L, _P]),
+    "sv_add_n": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "sv_axpby": (_I, [_P, _P, _P, _F, _F, _L, _P]),
+    "sv_relu_bwd": (_I, [_P, _P, _P, _L, _P]),
+    "sv_maxpool2d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "sv_maxpool2d_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "sv_avgpool2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sv_avgpool2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sv_decoder_seed_fwd": (_I, [_P, _P, _I, _I, _P]),
+    "sv_decoder_seed_bwd": (_I, [_P, _P, _I, _I, _P]),
+    "sv_maxpool3d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sv_maxpool3d_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sv_dropout": (_I, [_P, _P, _L, _F, _U, _P]),
+    "sv_droppath_scale": (_I, [_P, _I, _F, _U, _P]),
+    "sv_rowscale": (_I, [_P, _P, _P, _L, _I, _I, _P]),
+    "sv_dwconv2x2_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "sv_dwconv2x2_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "sv_upsample3to7_add_fwd": (_I, [_P, _P, _I, _P, _I, _I, _P]),
+    "sv_upsample3to7_bwd": (_I, [_P, _P, _I, _I, _P]),
+    "sv_decoder_head_fwd": (_I, [_P, _P, _P, _P, _P, _L, _P]),
+    "sv_decoder_head_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "sv_merge_views_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "sv_merge_views_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "sv_mean_views": (_I, [_P, _P, _I, _I, _I, _P]),
+    "sv_bce_logits": (_I, [_P, _P, _L, _P, _P, _P, _P]),
+    "sv_iou_counts": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+}
+EXPORTED_SYMBOLS = sorted(list(_PROTOS.keys()) + ["sv_last_error"])
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"swinvox_amd: {LIB_PATH} is missing - the HIP kernels are the product and there is no fallback. "
+                    "Build with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950).")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in _PROTOS.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            lib.sv_last_error.restype = C.c_char_p
+            lib.sv_last_error.argtypes = []
+            _lib = lib
+    return _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be fp32 (or uint8 for pool indices)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def check_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("swinvox_amd: tensors must live on the GPU (no CPU path exists in the product); got "
+                               f"device={t.device}")
+
+
+def call(name: str, *args) -> None:
+    """Invoke an entry point on the current torch stream; a non-zero return becomes a RuntimeError."""
+    lib = load()
+    rc = getattr(lib, name)(*args, _stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib.sv_last_error().decode()}")

@@ -1,0 +1,140 @@
+"""Shared machinery of the HIP-backed modules.
+
+Each public module (Encoder, Decoder, Merger, Refiner) is ONE autograd node: its forward runs a hand-written
+chain of HIP kernels and records a tape of device buffers, its backward walks the tape in reverse with the
+matching gradient kernels and returns the parameter gradients.  Parameters live in stock nn.Conv*/nn.Linear/
+nn.BatchNorm*/nn.LayerNorm holders so state_dict keys, init_weights (utils/helpers.py:20-44), optimizers,
+clip_grad_norm_ and checkpoints behave exactly as with the reference modules.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import hip, ops
+from ..ops import ACT_LRELU, ACT_NONE, ACT_RELU, BatchNormState, ConvSpec, call, empty, ptr, zeros
+
+
+class GradStore:
+    """Zero-initialised gradient accumulators for every parameter of a module (one flat buffer)."""
+
+    def __init__(self, params: Sequence[torch.Tensor]):
+        self.params = list(params)
+        total = sum(p.numel() for p in self.params)
+        # every slice starts on a 16-byte boundary
+        offs, o = [], 0
+        for p in self.params:
+            offs.append(o)
+            o += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(max(o, 4), dtype=torch.float32, device=self.params[0].device) if self.params else None
+        self._map: Dict[int, torch.Tensor] = {}
+        for p, of in zip(self.params, offs):
+            self._map[id(p)] = self.flat[of:of + p.numel()].view(p.shape)
+        del total
+
+    def __getitem__(self, p: torch.Tensor) -> torch.Tensor:
+        return self._map[id(p)]
+
+    def as_tuple(self):
+        return tuple(self._map[id(p)] if p.requires_grad else None for p in self.params)
+
+
+class _ModuleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, n_in, save, *args):
+        inputs = args[:n_in]
+        outs, tape = mod._fwd(*inputs, save=save)
+        ctx.mod, ctx.tape, ctx.n_in = mod, tape, n_in
+        ctx.in_needs = [isinstance(a, torch.Tensor) and a.requires_grad for a in inputs]
+        return outs
+
+    @staticmethod
+    def backward(ctx, *douts):
+        mod = ctx.mod
+        if ctx.tape is None:
+            raise RuntimeError("swinvox_amd: backward requested but the forward ran without a tape (no_grad?)")
+        grads = GradStore(mod._param_list())
+        d_inputs = mod._bwd(ctx.tape, grads, ctx.in_needs, *douts)
+        ctx.tape = None
+        return (None, None, None) + tuple(d_inputs) + grads.as_tuple()
+
+
+class HipModule(nn.Module):
+    """Base of the four drop-in modules.  Sub-classes implement _fwd(*inputs, save) -> (outputs, tape) and
+    _bwd(tape, grads, in_needs, *douts) -> d_inputs."""
+
+    stochastic = True  # dropout / drop-path active in train() (set False for deterministic gradient parity tests)
+
+    def _param_list(self) -> List[torch.Tensor]:
+        return list(self.parameters())
+
+    def _run(self, *inputs):
+        hip.check_cuda(*inputs)
+        hip.check_cuda(*self._param_list()[:1])
+        for t in inputs:
+            if t.dtype != torch.float32:
+                raise RuntimeError(f"swinvox_amd: expected float32 inputs, got {t.dtype}")
+        params = self._param_list()
+        save = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or any(t.requires_grad for t in inputs))
+        return _ModuleFn.apply(self, len(inputs), save, *[t.contiguous() for t in inputs], *params)
+
+    def _seed(self) -> int:
+        return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+
+class ConvBnAct:
+    """Conv/ConvTranspose (+bias) -> BatchNorm (train: batch statistics gathered in the contraction's epilogue)
+    -> activation, on channels-last data; forward and backward."""
+
+    def __init__(self, conv: nn.Module, bn: nn.Module, spec: ConvSpec, act: int, slope: float = 0.0):
+        self.conv, self.bn, self.spec, self.act, self.slope = conv, bn, spec, act, slope
+
+    def forward(self, x, n, in_grid, training, *, ldi=None, z=None, ldz=None, residual=None, ldr=0):
+        sp = self.spec
+        og = sp.out_grid(in_grid)
+        M = n * og[0] * og[1] * og[2]
+        wf = sp.pack_fwd(self.conv.weight)
+        y = empty(M, sp.cout, like=x)
+        st = BatchNormState(self.bn, M, training)
+        sp.forward(x, n, in_grid, wf, y, ldi=ldi, bias=self.conv.bias, stats=st.sums)
+        st.finalize()
+        if z is None:
+            z, ldz = empty(M, sp.cout, like=x), sp.cout
+        st.apply(y, sp.cout, z, ldz, self.act, self.slope, residual, ldr)
+        return z, og, (x, ldi, y, z, ldz, st, n, in_grid, M)
+
+    def backward(self, ctx, dz, lddz, grads, *, need_dx=True, dres=None, lddres=0, dx=None, lddx=None, dx_epi=None):
+        x, ldi, y, z, ldz, st, n, in_grid, M = ctx
+        sp = self.spec
+        dy = (zeros if sp.cout_mem != sp.cout else empty)(M, sp.cout_mem, like=dz)
+        st.backward(dz, lddz, z, ldz, y, sp.cout, dy, sp.cout_mem, grads[self.bn.weight], grads[self.bn.bias], self.act, self.slope,
+                    dres, lddres)
+        if self.conv.bias is not None:
+            ops.colsum(dy, M, sp.cout, sp.cout_mem, grads[self.conv.bias])
+        sp.wgrad(dy, x, n, in_grid, grads[self.conv.weight], lddy=sp.cout_mem, ldx=ldi)
+        if not need_dx:
+            return None
+        Min = n * in_grid[0] * in_grid[1] * in_grid[2]
+        if dx is None:
+            dx = (zeros if sp.cin_mem != sp.cin else empty)(Min, sp.cin_mem, like=dz)
+            lddx = sp.cin_mem
+        sp.dgrad(dy, n, in_grid, sp.pack_dgrad(self.conv.weight), dx, lddy=sp.cout_mem, lddx=lddx, **(dx_epi or {}))
+        return dx
+
+
+def conv_spec_of(m: nn.Module, **kw) -> ConvSpec:
+    """ConvSpec from a stock nn.Conv2d / nn.Conv3d / nn.ConvTranspose3d / nn.Linear holder."""
+    if isinstance(m, nn.Linear):
+        return ConvSpec.linear(m.in_features, m.out_features)
+    if isinstance(m, nn.Conv2d):
+        assert m.groups == 1 and m.dilation == (1, 1)
+        return ConvSpec.conv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, **kw)
+    if isinstance(m, nn.ConvTranspose3d):
+        assert m.groups == 1 and m.output_padding == (0, 0, 0)
+        return ConvSpec.conv3d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, transposed=True, **kw)
+    if isinstance(m, nn.Conv3d):
+        assert m.groups == 1
+        return ConvSpec.conv3d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, **kw)
+    raise TypeError(type(m))

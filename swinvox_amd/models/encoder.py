@@ -1,0 +1,234 @@
+"""Encoder on HIP kernels; mirrors reference models/encoder.py:14-164 (same constructor, attribute names,
+state_dict keys and forward signature: [B,V,3,224,224] -> [B,V,256,7,7]).
+
+The ResNet-50 trunk restates torchvision 0.21 resnet50 children[:7] (keys resnet.{0,1,4,5,6}.*); pretrained weights
+are not fetched (offline) - load a checkpoint with load_state_dict instead.
+"""
+from __future__ import annotations
+
+import logging
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import ACT_NONE, ACT_RELU, ConvSpec, call, empty, ptr, zeros
+from ._base import ConvBnAct, HipModule, conv_spec_of
+from .cross_view_attention import CrossViewAttention
+from .swin_transformer import SwinTransformer, swin_backward, swin_forward
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, inplanes, planes, stride, with_downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if with_downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+        self.stride = stride
+        self._c1 = ConvBnAct(self.conv1, self.bn1, conv_spec_of(self.conv1), ACT_RELU)
+        self._c2 = ConvBnAct(self.conv2, self.bn2, conv_spec_of(self.conv2), ACT_RELU)
+        self._c3 = ConvBnAct(self.conv3, self.bn3, conv_spec_of(self.conv3), ACT_RELU)
+        self._cd = ConvBnAct(self.downsample[0], self.downsample[1], conv_spec_of(self.downsample[0]), ACT_NONE) if with_downsample else None
+
+    def fwd(self, x, n, grid, training):
+        a, g1, c1 = self._c1.forward(x, n, grid, training)
+        b, g2, c2 = self._c2.forward(a, n, g1, training)
+        idt, cd = x, None
+        if self._cd is not None:
+            idt, _, cd = self._cd.forward(x, n, grid, training)
+        out, g3, c3 = self._c3.forward(b, n, g2, training, residual=idt, ldr=self.conv3.out_channels)
+        return out, g3, (c1, c2, c3, cd)
+
+    def bwd(self, ctx, dout, grads):
+        c1, c2, c3, cd = ctx
+        Co = self.conv3.out_channels
+        didt = empty(dout.shape[0], Co, like=dout)
+        db = self._c3.backward(c3, dout, Co, grads, dres=didt, lddres=Co)
+        da = self._c2.backward(c2, db, self.conv2.out_channels, grads)
+        dx = self._c1.backward(c1, da, self.conv1.out_channels, grads)
+        if cd is not None:
+            dx2 = self._cd.backward(cd, didt, Co, grads)
+            call("sv_axpby", ptr(dx), ptr(dx2), ptr(dx), 1.0, 1.0, dx.numel())
+        else:
+            call("sv_axpby", ptr(dx), ptr(didt), ptr(dx), 1.0, 1.0, dx.numel())
+        return dx
+
+
+def _res_layer(inplanes, planes, blocks, stride):
+    return nn.Sequential(Bottleneck(inplanes, planes, stride, True), *[Bottleneck(planes * 4, planes, 1, False) for _ in range(blocks - 1)])
+
+
+class Encoder(HipModule):
+    def __init__(self, cfg, variant: str = "tiny"):
+        super().__init__()
+        self.cfg = cfg
+        n = cfg.NETWORK
+        logging.info("swinvox_amd: ResNet-50 / Swin weights are randomly initialised (no network); load a checkpoint to restore them")
+        self.resnet = nn.Sequential(
+            nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+            nn.MaxPool2d(3, stride=2, padding=1), _res_layer(64, 64, 3, 1), _res_layer(256, 128, 4, 2), _res_layer(512, 256, 6, 2))
+        self.swin_transformer = SwinTransformer(cfg, in_channels=3, img_size=224, pretrained=True, variant=variant)
+        self.resnet_reduce = nn.Conv2d(1024, 256, kernel_size=1)
+        if n.USE_SWIN_T_MULTI_STAGE:
+            self.swin_stage_reduces = nn.ModuleList([nn.Conv2d(ch, 256, kernel_size=1) for ch in self.swin_transformer.out_channels])
+            chains = []
+            for i in n.SWIN_T_STAGES:
+                nblk = 3 - i if i <= 2 else 0
+                mods = []
+                for _ in range(nblk):
+                    mods += [nn.Conv2d(256, 256, kernel_size=3, stride=2, padding=1), nn.BatchNorm2d(256), nn.ReLU()]
+                chains.append(nn.Sequential(*mods) if nblk else nn.Identity())
+            self.swin_downsamples = nn.ModuleList(chains)
+        else:
+            self.swin_reduce = nn.Conv2d(self.swin_transformer.out_channels[-1], 256, kernel_size=1)
+        self.cross_view_attention = CrossViewAttention(cfg, in_channels=512) if n.USE_CROSS_VIEW_ATTENTION else None
+
+        def cbr(cin):
+            return nn.Sequential(nn.Conv2d(cin, 256, kernel_size=3, padding=1), nn.BatchNorm2d(256), nn.ReLU())
+
+        self.fusion_layer, self.layer1, self.layer2, self.layer3 = cbr(512), cbr(256), cbr(256), cbr(256)
+        # kernel-chain helpers (no parameters of their own)
+        self._stem = ConvBnAct(self.resnet[0], self.resnet[1], conv_spec_of(self.resnet[0]), ACT_RELU)
+        self._s_rr = ConvSpec.linear(1024, 256)
+        self._post = [ConvBnAct(m[0], m[1], conv_spec_of(m[0]), ACT_RELU) for m in (self.fusion_layer, self.layer1, self.layer2, self.layer3)]
+        if n.USE_SWIN_T_MULTI_STAGE:
+            self._s_red = [ConvSpec.linear(c.in_channels, 256) for c in self.swin_stage_reduces]
+            self._chains = [[ConvBnAct(ch[3 * j], ch[3 * j + 1], conv_spec_of(ch[3 * j]), ACT_RELU) for j in range(len(ch) // 3)]
+                            if not isinstance(ch, nn.Identity) else [] for ch in self.swin_downsamples]
+        else:
+            self._s_red1 = ConvSpec.linear(self.swin_reduce.in_channels, 256)
+
+    def forward(self, rendering_images):
+        assert rendering_images.dim() == 5 and rendering_images.shape[2] == 3, "expected [B, V, 3, H, W]"
+        assert tuple(rendering_images.shape[-2:]) == (224, 224), "swinvox_amd: images must be 224x224 (reference cfg.CONST.IMG_H/W)"
+        return self._run(rendering_images)
+
+    # ------------------------------------------------------------------------------------------------
+    def _fwd(self, images, save):
+        B, V = images.shape[:2]
+        I = B * V
+        images = images.contiguous()
+        tr, sto = self.training, self.stochastic
+        seeds = self._seed
+        multi = self.cfg.NETWORK.USE_SWIN_T_MULTI_STAGE
+        img = empty(I, 224 * 224, 3, like=images)
+        ops.transpose(images, img, I, 3, 224 * 224)                       # NCHW -> NHWC (coalesced both ways)
+        # ---- ResNet trunk
+        x, g, c_stem = self._stem.forward(img, I, (1, 224, 224), tr)
+        mp = empty(I * 56 * 56, 64, like=x)
+        mp_idx = torch.empty(I * 56 * 56 * 64, dtype=torch.uint8, device=x.device)
+        call("sv_maxpool2d_fwd", ptr(x), ptr(mp), ptr(mp_idx), I, 112, 112, 64)
+        x, g = mp, (1, 56, 56)
+        c_blocks = []
+        for li in (4, 5, 6):
+            for blk in self.resnet[li]:
+                x, g, c = blk.fwd(x, I, g, tr)
+                c_blocks.append((blk, c))
+        res_feat = x                                                       # [I*196, 1024]
+        rr = empty(I * 196, 256, like=x)
+        ops.linear_fwd(res_feat, I * 196, self._s_rr, self.resnet_reduce.weight, rr, bias=self.resnet_reduce.bias)
+        cat = empty(I * 49, 512, like=x)
+        call("sv_avgpool2_fwd", ptr(rr), ptr(cat), I, 14, 14, 256, 512, 0)
+        # ---- Swin branch
+        feats, swin_tape = swin_forward(self.swin_transformer, img, I, tr, sto, seeds)
+        neck = []
+        if multi:
+            outs = []
+            for k, f in enumerate(feats):
+                hw = self.swin_transformer.out_spatial[k]
+                red = empty(I * hw * hw, 256, like=x)
+                ops.linear_fwd(f, I * hw * hw, self._s_red[k], self.swin_stage_reduces[k].weight, red, bias=self.swin_stage_reduces[k].bias)
+                y, gg, cc = red, (1, hw, hw), []
+                for cba in self._chains[k]:
+                    y, gg, c = cba.forward(y, I, gg, tr)
+                    cc.append(c)
+                assert gg == (1, 7, 7), "multi-stage neck must end at 7x7"
+                outs.append(y)
+                neck.append((f, red, cc))
+            cat_s = cat[:, 256:]
+            if len(outs) == 1:
+                outs = outs + [zeros(I * 49, 256, like=x)]
+            call("sv_add_n", ptr(outs[0]), ptr(outs[1]), ptr(outs[2]) if len(outs) > 2 else None, ptr(outs[3]) if len(outs) > 3 else None,
+                 ptr(cat_s), I * 49, 256, 512)
+        else:
+            f = feats if not isinstance(feats, list) else feats[-1]
+            ops.linear_fwd(f, I * 49, self._s_red1, self.swin_reduce.weight, cat, ldc=512, col_off=256, bias=self.swin_reduce.bias)
+            neck.append((f, None, None))
+        # ---- cross-view attention
+        c_cva = None
+        y = cat
+        if self.cross_view_attention is not None:
+            y, c_cva = self.cross_view_attention.cva_forward(cat, B, V, tr, sto, seeds)
+        # ---- fusion + 3 conv blocks @7x7
+        c_post = []
+        g = (1, 7, 7)
+        for cba in self._post:
+            y, g, c = cba.forward(y, I, g, tr)
+            c_post.append(c)
+        out = empty(B, V, 256, 7, 7, like=x)
+        ops.transpose(y, out, I, 49, 256)                                  # [I][49][256] -> [I][256][49]
+        tape = (B, V, c_stem, mp_idx, c_blocks, res_feat, rr, swin_tape, neck, c_cva, c_post) if save else None
+        return out, tape
+
+    def _bwd(self, tape, grads, in_needs, dout):
+        B, V, c_stem, mp_idx, c_blocks, res_feat, rr, swin_tape, neck, c_cva, c_post = tape
+        I = B * V
+        multi = self.cfg.NETWORK.USE_SWIN_T_MULTI_STAGE
+        dy = empty(I * 49, 256, like=dout)
+        ops.transpose(dout.contiguous(), dy, I, 256, 49)                   # [I][256][49] -> [I][49][256]
+        for cba, c in zip(reversed(self._post), reversed(c_post)):
+            dy = cba.backward(c, dy, 256, grads)
+        dcat = dy                                                          # [I*49, 512]
+        if c_cva is not None:
+            dcat = self.cross_view_attention.cva_backward(c_cva, dcat, grads)
+        # ---- Swin neck
+        dcat_s = dcat[:, 256:]
+        if multi:
+            dfeats = []
+            for k, (f, red, cc) in enumerate(neck):
+                hw = self.swin_transformer.out_spatial[k]
+                d, ld = dcat_s, 512
+                for cba, c in zip(reversed(self._chains[k]), reversed(cc)):
+                    d = cba.backward(c, d, ld, grads)
+                    ld = 256
+                conv = self.swin_stage_reduces[k]
+                sp = self._s_red[k]
+                rows = I * hw * hw
+                sp.wgrad(d, f, rows, (1, 1, 1), grads[conv.weight], lddy=ld)
+                ops.colsum(d, rows, 256, ld, grads[conv.bias])
+                df = empty(rows, sp.cin, like=dout)
+                sp.dgrad(d, rows, (1, 1, 1), sp.pack_dgrad(conv.weight), df, lddy=ld)
+                dfeats.append(df)
+        else:
+            f = neck[0][0]
+            sp = self._s_red1
+            sp.wgrad(dcat_s, f, I * 49, (1, 1, 1), grads[self.swin_reduce.weight], lddy=512)
+            ops.colsum(dcat_s, I * 49, 256, 512, grads[self.swin_reduce.bias])
+            df = empty(I * 49, sp.cin, like=dout)
+            sp.dgrad(dcat_s, I * 49, (1, 1, 1), sp.pack_dgrad(self.swin_reduce.weight), df, lddy=512)
+            dfeats = [None] * (len(self.swin_transformer.layer_norm) - 1) + [df]
+            for i in range(len(dfeats) - 1):   # unused heads of the single-stage path receive zero gradient
+                hw, ch = self.swin_transformer.out_spatial[i], self.swin_transformer.out_channels[i]
+                dfeats[i] = zeros(I * hw * hw, ch, like=dout)
+        swin_backward(self.swin_transformer, swin_tape, dfeats, I, grads)
+        # ---- ResNet branch
+        drr = empty(I * 196, 256, like=dout)
+        call("sv_avgpool2_bwd", ptr(dcat), ptr(drr), I, 14, 14, 256, 512, 0)
+        self._s_rr.wgrad(drr, res_feat, I * 196, (1, 1, 1), grads[self.resnet_reduce.weight])
+        ops.colsum(drr, I * 196, 256, 256, grads[self.resnet_reduce.bias])
+        d = empty(I * 196, 1024, like=dout)
+        self._s_rr.dgrad(drr, I * 196, (1, 1, 1), self._s_rr.pack_dgrad(self.resnet_reduce.weight), d)
+        for blk, c in reversed(c_blocks):
+            d = blk.bwd(c, d, grads)
+        dmp = zeros(I * 112 * 112, 64, like=dout)
+        call("sv_maxpool2d_bwd", ptr(d), ptr(mp_idx), ptr(dmp), I, 112, 112, 64)
+        self._stem.backward(c_stem, dmp, 64, grads, need_dx=False)
+        return (None,)

@@ -1,0 +1,210 @@
+"""Host-side operator layer over the C ABI: geometry bookkeeping, weight packing, forward / data-grad /
+weight-grad calls of the contraction engine, and the normalisation / pooling wrappers.
+
+Everything here only enqueues HIP kernels on the current torch stream; torch is used for buffer
+allocation (caching allocator) and nothing else.  All activations are fp32, channels-last.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import hip
+from .hip import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, Epilogue, Geom, call, ptr  # noqa: F401
+
+_STATE = {"math": hip.MATH_F32}
+
+
+def set_math(mode: str) -> None:
+    """'f32' = exact fp32 MFMA (parity mode); 'bf16' = bf16 MFMA inputs, fp32 accumulate and I/O."""
+    _STATE["math"] = {"f32": hip.MATH_F32, "fp32": hip.MATH_F32, "bf16": hip.MATH_BF16}[mode]
+
+
+def get_math() -> str:
+    return "bf16" if _STATE["math"] == hip.MATH_BF16 else "f32"
+
+
+def empty(*shape, like: torch.Tensor = None, device=None) -> torch.Tensor:
+    return torch.empty(*shape, dtype=torch.float32, device=like.device if like is not None else device)
+
+
+def zeros(*shape, like: torch.Tensor = None, device=None) -> torch.Tensor:
+    return torch.zeros(*shape, dtype=torch.float32, device=like.device if like is not None else device)
+
+
+def _t3(v) -> Tuple[int, int, int]:
+    if isinstance(v, int):
+        return (v, v, v)
+    v = tuple(int(x) for x in v)
+    return (1,) * (3 - len(v)) + v if len(v) < 3 else v
+
+
+def _pad3(v, fill) -> Tuple[int, int, int]:
+    """2-D parameters are lifted to 3-D with a unit depth axis."""
+    if isinstance(v, int):
+        return (v, v, v)
+    v = tuple(int(x) for x in v)
+    return (fill,) * (3 - len(v)) + v
+
+
+def _epilogue(ldc, col_off=0, bias=None, residual=None, ldr=0, row_scale=None, rows_per_scale=1, pre_act=None, stats=None,
+              act=ACT_NONE, slope=0.0, act_grad_src=None, act_grad_kind=ACT_NONE) -> Epilogue:
+    return Epilogue(ptr(bias), ptr(residual), ldr, ptr(row_scale), rows_per_scale, ptr(pre_act), ptr(stats), act, slope,
+                    ptr(act_grad_src), act_grad_kind, ldc, col_off)
+
+
+@dataclass
+class ConvSpec:
+    """Geometry of one Linear / Conv / ConvTranspose layer (3-D form; 2-D layers use a unit depth axis)."""
+    cin: int
+    cout: int
+    k: Tuple[int, int, int] = (1, 1, 1)
+    s: Tuple[int, int, int] = (1, 1, 1)
+    p: Tuple[int, int, int] = (0, 0, 0)
+    transposed: bool = False
+    cin_mem: Optional[int] = None    # channels the input activation holds in memory (zero-padded), default cin
+    cout_mem: Optional[int] = None   # channels the output-gradient holds in memory, default cout
+
+    def __post_init__(self):
+        self.cin_mem = self.cin_mem or self.cin
+        self.cout_mem = self.cout_mem or self.cout
+        self.taps = self.k[0] * self.k[1] * self.k[2]
+
+    @staticmethod
+    def conv2d(cin, cout, k, s=1, p=0, **kw):
+        return ConvSpec(cin, cout, _pad3(k if not isinstance(k, int) else (k, k), 1), _pad3(s if not isinstance(s, int) else (s, s), 1),
+                        _pad3(p if not isinstance(p, int) else (p, p), 0), False, **kw)
+
+    @staticmethod
+    def conv3d(cin, cout, k, s=1, p=0, transposed=False, **kw):
+        return ConvSpec(cin, cout, _t3(k), _t3(s), _t3(p), transposed, **kw)
+
+    @staticmethod
+    def linear(cin, cout):
+        return ConvSpec(cin, cout)
+
+    def out_grid(self, g):
+        if self.transposed:
+            return tuple((g[i] - 1) * self.s[i] - 2 * self.p[i] + self.k[i] for i in range(3))
+        return tuple((g[i] + 2 * self.p[i] - self.k[i]) // self.s[i] + 1 for i in range(3))
+
+    # ---- weight packs (device copies made once per step) -------------------------------------------
+    def pack_fwd(self, w: torch.Tensor) -> torch.Tensor:
+        """[cout][tap][cin_mem] from the native parameter layout ([cout,cin,k..] conv / [cin,cout,k..] tconv)."""
+        if not self.transposed and self.taps == 1 and self.cin_mem == self.cin:
+            return w  # Linear / 1x1 conv: the native layout already is the packed layout
+        out = empty(self.cout * self.taps * self.cin_mem, like=w)
+        A, B = (self.cin, self.cout) if self.transposed else (self.cout, self.cin)
+        call("sv_pack_weight", ptr(w), ptr(out), A, B, self.taps, 1 if self.transposed else 0, self.cin_mem)
+        return out
+
+    def pack_dgrad(self, w: torch.Tensor) -> torch.Tensor:
+        """[cin][tap][cout_mem]."""
+        out = empty(self.cin * self.taps * self.cout_mem, like=w)
+        A, B = (self.cin, self.cout) if self.transposed else (self.cout, self.cin)
+        call("sv_pack_weight", ptr(w), ptr(out), A, B, self.taps, 0 if self.transposed else 1, self.cout_mem)
+        return out
+
+    def _geom(self, n, gathered_grid, produced_grid, ci, co, ldi) -> Geom:
+        return Geom(n, *gathered_grid, *produced_grid, ci, co, *self.k, *self.s, *self.p, ldi)
+
+    # ---- forward ------------------------------------------------------------------------------------
+    def forward(self, x, n, in_grid, w_packed, out, *, ldi=None, ldc=None, **epi):
+        og = self.out_grid(in_grid)
+        g = self._geom(n, in_grid, og, self.cin_mem, self.cout, ldi or self.cin_mem)
+        e = _epilogue(ldc or self.cout, **epi)
+        call("sv_tconv_gather" if self.transposed else "sv_conv_gather", ptr(x), ptr(w_packed), ptr(out), C.byref(g), C.byref(e),
+             _STATE["math"])
+        return og
+
+    # ---- data gradient: dx[., cin] from dy[., cout_mem] -----------------------------------------------
+    def dgrad(self, dy, n, in_grid, w_dgrad, dx, *, lddy=None, lddx=None, **epi):
+        og = self.out_grid(in_grid)
+        g = self._geom(n, og, in_grid, self.cout_mem, self.cin, lddy or self.cout_mem)
+        e = _epilogue(lddx or self.cin_mem, **epi)
+        call("sv_conv_gather" if self.transposed else "sv_tconv_gather", ptr(dy), ptr(w_dgrad), ptr(dx), C.byref(g), C.byref(e),
+             _STATE["math"])
+
+    # ---- weight gradient, accumulated into dw (native layout) ------------------------------------------
+    def wgrad(self, dy, x, n, in_grid, dw, *, lddy=None, ldx=None):
+        og = self.out_grid(in_grid)
+        if self.transposed:   # anchor = x (cin), gathered = dy (cout)
+            g = self._geom(n, og, in_grid, self.cout_mem, self.cin, lddy or self.cout_mem)
+            call("sv_conv_wgrad", ptr(x), ldx or self.cin_mem, ptr(dy), ptr(dw), C.byref(g), self.cout, _STATE["math"])
+        else:                 # anchor = dy (cout), gathered = x (cin)
+            g = self._geom(n, in_grid, og, self.cin_mem, self.cout, ldx or self.cin_mem)
+            call("sv_conv_wgrad", ptr(dy), lddy or self.cout_mem, ptr(x), ptr(dw), C.byref(g), self.cin, _STATE["math"])
+
+
+def colsum(x, rows, cols, ld, out, accumulate=True):
+    call("sv_colsum", ptr(x), rows, cols, ld, ptr(out), 1 if accumulate else 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Linear helpers (rows x K) used by the Swin blocks
+# ---------------------------------------------------------------------------------------------------
+def linear_fwd(x, rows, spec: ConvSpec, w, out, **epi):
+    spec.forward(x, rows, (1, 1, 1), w, out, **epi)
+
+
+def linear_dgrad(dy, rows, spec: ConvSpec, w_t, dx, **epi):
+    spec.dgrad(dy, rows, (1, 1, 1), w_t, dx, **epi)
+
+
+def linear_wgrad(dy, x, rows, spec: ConvSpec, dw, db=None):
+    spec.wgrad(dy, x, rows, (1, 1, 1), dw)
+    if db is not None:
+        colsum(dy, rows, spec.cout, spec.cout_mem, db)
+
+
+# ---------------------------------------------------------------------------------------------------
+# normalisation wrappers
+# ---------------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, rows, Cdim, merge_hw=(0, 0), eps=1e-5):
+    y = empty(rows, Cdim, like=x)
+    mean = empty(rows, like=x)
+    rstd = empty(rows, like=x)
+    call("sv_layernorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, Cdim, eps, merge_hw[0], merge_hw[1])
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cdim, merge_hw=(0, 0), accumulate_dx=False):
+    call("sv_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), rows, Cdim,
+         merge_hw[0], merge_hw[1], 1 if accumulate_dx else 0)
+
+
+class BatchNormState:
+    """Per-call state of one BatchNorm layer on channels-last [M, C] data."""
+
+    def __init__(self, bn: torch.nn.Module, M: int, training: bool):
+        self.bn, self.M, self.training, self.C = bn, M, training, bn.num_features
+        dev = bn.weight.device
+        self.sums = zeros(2 * self.C, device=dev) if training else None
+        buf = empty(4 * self.C, device=dev)
+        self.scale, self.shift, self.mean, self.rstd = buf[:self.C], buf[self.C:2 * self.C], buf[2 * self.C:3 * self.C], buf[3 * self.C:]
+
+    def finalize(self):
+        bn = self.bn
+        if self.training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        call("sv_bn_finalize", ptr(self.sums), self.M, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+             float(mom), float(bn.eps), 1 if self.training else 0, ptr(self.scale), ptr(self.shift), ptr(self.mean), ptr(self.rstd), self.C)
+
+    def apply(self, x, ldx, y, ldy, act=ACT_NONE, slope=0.0, residual=None, ldr=0):
+        call("sv_scale_shift_act", ptr(x), ldx, ptr(self.scale), ptr(self.shift), ptr(residual), ldr, ptr(y), ldy, self.M, self.C, act, slope)
+
+    def backward(self, dz, lddz, z, ldz, x, ldx, dx, lddx, dgamma, dbeta, act=ACT_NONE, slope=0.0, dres=None, lddres=0):
+        ws = empty(2 * self.C, like=dz)
+        call("sv_bn_bwd", ptr(dz), lddz, ptr(z), ldz, ptr(x), ldx, ptr(self.bn.weight), ptr(self.mean), ptr(self.rstd), self.M, self.C,
+             act, slope, 1 if self.training else 0, ptr(dx), lddx, ptr(dres), lddres, ptr(dgamma), ptr(dbeta), ptr(ws))
+
+
+def transpose(src, dst, batch, R, Cc, lds=None, ldd=None, sb=None, db=None):
+    """dst[b][c][r] = src[b][r][c]"""
+    lds = lds or Cc
+    ldd = ldd or R
+    call("sv_transpose", ptr(src), ptr(dst), batch, R, Cc, lds, ldd, sb if sb is not None else R * lds, db if db is not None else Cc * ldd)

@@ -1,0 +1,214 @@
+"""Module-level parity (through the C ABI) of the HIP Encoder/Decoder/Merger/Refiner against the CPU oracle and the
+committed golden vectors.  Tolerances follow BASELINE.json: 1e-3 fp32 (relative to max|ref| per module, absolute
+on final logits), thresholded occupancy bit-exact outside a 1e-3 band around logit(th)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O  # noqa: E402
+import swinvox_amd as S  # noqa: E402
+from swinvox_amd import ops  # noqa: E402
+from swinvox_amd.models import Decoder, Encoder, Merger, Refiner  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def synth_images(B, V, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (0.5 * torch.randn(B, V, 3, 224, 224, generator=g)).clamp(-1, 1)
+
+
+def synth_gt(B, seed):
+    g = torch.Generator().manual_seed(seed + 1000)
+    return (torch.rand(B, 32, 32, 32, generator=g) < 0.10).float()
+
+
+def no_stochastic(nets):
+    for n in nets:
+        for m in n.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            if isinstance(m, O.model.SwinBlock):
+                m.dp = 0.0
+
+
+@pytest.fixture(scope="module")
+def nets(dev):
+    """Oracle nets with the golden recipe (seeded weights + calibration) and HIP nets holding the same state."""
+    torch.manual_seed(0)
+    cfg = O.default_cfg()
+    onets = [O.Encoder(cfg), O.Decoder(cfg), O.Merger(cfg), O.Refiner(cfg)]
+    for i, n in enumerate(onets):
+        O.seeded_weights_(n, seed=100 + i)
+    O.calibrate_(onets, synth_images(2, 2, 1234))
+    for n in onets:
+        n.eval()
+    pcfg = S.default_cfg()
+    pnets = [Encoder(pcfg), Decoder(pcfg), Merger(pcfg), Refiner(pcfg)]
+    for p, o in zip(pnets, onets):
+        p.load_state_dict(o.state_dict(), strict=True)
+        p.to(dev).eval()
+    ops.set_math("f32")
+    return onets, pnets
+
+
+def test_tail_modules_eval_and_train(dev, nets):
+    onets, pnets = nets
+    g = torch.Generator().manual_seed(3)
+    feat = torch.randn(2, 3, 256, 7, 7, generator=g)
+    for mode in ("eval", "train"):
+        # fresh copies so BN running stats of the shared fixture stay untouched
+        import copy
+        o_dec, o_mer, o_ref = (copy.deepcopy(n) for n in onets[1:])
+        p_dec, p_mer, p_ref = Decoder(S.default_cfg()), Merger(S.default_cfg()), Refiner(S.default_cfg())
+        for p, o in ((p_dec, o_dec), (p_mer, o_mer), (p_ref, o_ref)):
+            p.load_state_dict(o.state_dict()); p.to(dev)
+            p.train(mode == "train"); o.train(mode == "train")
+        with torch.no_grad():
+            raw_o, vol_o = o_dec(feat)
+            mer_o = o_mer(raw_o, vol_o)
+            ref_o = o_ref(mer_o)
+            raw_p, vol_p = p_dec(feat.to(dev))
+            mer_p = p_mer(raw_p, vol_p)
+            ref_p = p_ref(mer_p)
+        assert raw_p.shape == raw_o.shape and vol_p.shape == vol_o.shape
+        assert rel(raw_p, raw_o) < 1e-3 and rel(vol_p, vol_o) < 1e-3, mode
+        assert rel(mer_p, mer_o) < 1e-3 and rel(ref_p, ref_o) < 1e-3, mode
+        if mode == "train":   # running statistics were updated identically
+            for (k, a), (_, b) in zip(p_ref.state_dict().items(), o_ref.state_dict().items()):
+                if "running" in k:
+                    assert rel(a, b) < 1e-3, k
+
+
+def test_tail_backward(dev, nets):
+    import copy
+    onets, _ = nets
+    g = torch.Generator().manual_seed(4)
+    B, V = 2, 2
+    o_dec, o_mer, o_ref = (copy.deepcopy(n).train() for n in onets[1:])
+    p_dec, p_mer, p_ref = Decoder(S.default_cfg()), Merger(S.default_cfg()), Refiner(S.default_cfg())
+    for p, o in ((p_dec, o_dec), (p_mer, o_mer), (p_ref, o_ref)):
+        p.load_state_dict(o.state_dict()); p.to(dev).train()
+    feat = torch.randn(B, V, 256, 7, 7, generator=g)
+    gt = synth_gt(B, 7)
+    f1 = feat.clone().requires_grad_(True)
+    raw, vol = o_dec(f1)
+    mer = o_mer(raw, vol)
+    loss_o = O.bce_logits(mer, gt) + O.bce_logits(o_ref(mer), gt)
+    loss_o.backward()
+    f2 = feat.clone().to(dev).requires_grad_(True)
+    raw, vol = p_dec(f2)
+    mer = p_mer(raw, vol)
+    loss_p = torch.nn.functional.binary_cross_entropy_with_logits(mer, gt.to(dev)) + \
+        torch.nn.functional.binary_cross_entropy_with_logits(p_ref(mer), gt.to(dev))
+    loss_p.backward()
+    assert abs(float(loss_p) - float(loss_o)) < 1e-4
+    assert rel(f2.grad, f1.grad) < 2e-3
+    worst = ("", 0.0)
+    for p, o in ((p_dec, o_dec), (p_mer, o_mer), (p_ref, o_ref)):
+        for (k, a), (_, b) in zip(p.named_parameters(), o.named_parameters()):
+            r = float((a.grad.cpu() - b.grad).abs().max() / (b.grad.abs().max() + 1e-20))
+            # conv biases feeding a train-mode BN have an exactly-zero true gradient: compare absolutely there
+            if b.grad.abs().max() < 1e-6:
+                r = float((a.grad.cpu() - b.grad).abs().max())
+            if r > worst[1]:
+                worst = (f"{type(p).__name__}.{k}", r)
+    assert worst[1] < 5e-3, worst
+
+
+@pytest.mark.parametrize("B,V", [(2, 1), (1, 2)])
+def test_full_forward_vs_oracle_and_golden(dev, nets, B, V):
+    onets, pnets = nets
+    man = json.load(open(os.path.join(GOLD, "manifest.json")))["cases"][f"B{B}_V{V}"]
+    x, gt = synth_images(B, V, man["seed"]), synth_gt(B, man["seed"])
+    gold = np.load(os.path.join(GOLD, f"case_B{B}_V{V}.npz"))
+    enc, dec, mer, ref = pnets
+    with torch.no_grad():
+        f = enc(x.to(dev))
+        raw, vol = dec(f)
+        merged = mer(raw, vol)
+        refined = ref(merged)
+        of = onets[0](x)
+        oraw, ovol = onets[1](of)
+        omerged = onets[2](oraw, ovol)
+        orefined = onets[3](omerged)
+    # HIP vs oracle on this machine
+    assert rel(f, of) < 1e-3
+    assert rel(raw, oraw) < 1e-3 and rel(vol, ovol) < 1e-3 and rel(merged, omerged) < 1e-3
+    assert float((refined.cpu() - orefined).abs().max()) < 1e-3 * max(1.0, float(orefined.abs().max()))
+    # HIP vs the committed golden vectors (made in the build container from the pinned oracle)
+    assert rel(f, torch.from_numpy(gold["features"])) < 1e-3
+    assert rel(refined, torch.from_numpy(gold["refined"])) < 2e-3
+    # thresholded occupancy: bit-exact outside a 1e-3 band around logit(th); IoU within 1e-3
+    excluded = 0
+    for th in (0.2, 0.3, 0.4, 0.5):
+        lt = math.log(th / (1 - th))
+        band = (orefined - lt).abs() <= 1e-3
+        excluded += int(band.sum())
+        a = torch.sigmoid(refined.cpu()) >= th
+        b = torch.sigmoid(orefined) >= th
+        assert bool((a == b)[~band].all())
+    assert excluded < 0.01 * orefined.numel() * 4
+    iou_p = O.iou_at_thresholds(refined.cpu(), gt)
+    assert np.abs(np.array(iou_p) - gold["iou"]).max() < 1e-3
+
+
+def test_train_step_gradients_vs_oracle(dev, nets):
+    """One full training step (core/train.py:226-272 semantics, dropout/drop-path off): loss and every gradient."""
+    import copy
+    onets, _ = nets
+    B, V = 2, 2
+    ocp = [copy.deepcopy(n).train() for n in onets]
+    no_stochastic(ocp)
+    pcfg = S.default_cfg()
+    pn = [Encoder(pcfg), Decoder(pcfg), Merger(pcfg), Refiner(pcfg)]
+    for p, o in zip(pn, ocp):
+        p.load_state_dict(o.state_dict()); p.to(dev).train(); p.stochastic = False
+    x, gt = synth_images(B, V, 44), synth_gt(B, 44)
+    total_o, el_o, rl_o, _, _ = O.train_step_loss(ocp, O.default_cfg(), x, gt)
+    total_o.backward()
+    xd, gd = x.to(dev).clamp(-1, 1), gt.to(dev)
+    raw, vol = pn[1](pn[0](xd))
+    merged = pn[2](raw, vol)
+    el = torch.nn.functional.binary_cross_entropy_with_logits(merged, gd)
+    rl = torch.nn.functional.binary_cross_entropy_with_logits(pn[3](merged), gd)
+    (el + rl).backward()
+    assert abs(float(el) - float(el_o)) < 1e-4 and abs(float(rl) - float(rl_o)) < 1e-4
+    gold = json.load(open(os.path.join(GOLD, "train_step_B2_V2.json")))
+    assert abs(float(el + rl) - gold["total"]) < 1e-3
+    bad = []
+    for tag, p, o in zip(("encoder", "decoder", "merger", "refiner"), pn, ocp):
+        for (k, a), (_, b) in zip(p.named_parameters(), o.named_parameters()):
+            ref = b.grad
+            scale = float(ref.abs().max())
+            err = float((a.grad.cpu() - ref).abs().max())
+            # gradients that are analytically zero (biases in front of a train-mode BatchNorm) are compared absolutely
+            ok = err <= 2e-2 * scale + 1e-7 if scale > 1e-6 else err < 1e-5
+            if not ok:
+                bad.append((f"{tag}.{k}", err, scale))
+    assert not bad, bad[:10]
+
+
+def test_single_stage_config(dev):
+    """USE_SWIN_T_MULTI_STAGE=False / SWIN_T_STAGES=[3] path (models/encoder.py:77,140) and V=1 cross-view attention."""
+    cfg_o = O.default_cfg(); cfg_o.NETWORK.USE_SWIN_T_MULTI_STAGE = False; cfg_o.NETWORK.SWIN_T_STAGES = [3]
+    cfg_p = S.default_cfg(); cfg_p.NETWORK.USE_SWIN_T_MULTI_STAGE = False; cfg_p.NETWORK.SWIN_T_STAGES = [3]
+    o, p = O.Encoder(cfg_o), Encoder(cfg_p)
+    O.seeded_weights_(o, seed=9)
+    o.eval()
+    p.load_state_dict(o.state_dict(), strict=True)
+    p.to(dev).eval()
+    x = synth_images(1, 1, 5)
+    with torch.no_grad():
+        assert rel(p(x.to(dev)), o(x)) < 1e-3
