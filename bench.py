@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""views/sec, forward+backward, SwinVox-T 224^2 -> 32^3 voxels, n_views=8 (BASELINE.json metric) on N MI355X.
+
+One "step" = one pass of the hot path over one synthetic batch: Encoder -> Decoder -> Merger -> Refiner forward,
+two BCE-with-logits losses, full backward (reference core/train.py:226-272 without the optimizer), plus - for
+N > 1 - the bucketed RCCL gradient all-reduce.  Workload per GPU (weak scaling): B samples x V=8 views of
+224x224 (BASELINE config "Full pipeline ... n_views=8, 1xMI355X"), train mode (dropout / drop-path / batch-stat
+BatchNorm active), inputs resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# dense MFMA peaks (MI355X_MICROARCH.md): fp32-input MFMA 157.3 TFLOP/s, bf16 ~2500 TFLOP/s; HBM3E 8 TB/s
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
+FWD_GFLOP_PER_VIEW = {1: 21.0, 8: 19.4, 24: 19.3}   # forward; fwd+bwd = 3x
+
+
+def cpu_baseline(views: int, threads: int):
+    """The CPU oracle (our restatement of the reference path, pinned against it in the build container) timed on this
+    host's cores on a bounded sample: one fwd+bwd step of B=1 x `views` views, fp32."""
+    import oracle as O
+    torch.set_num_threads(threads)
+    cfg = O.default_cfg()
+    nets = [O.Encoder(cfg), O.Decoder(cfg), O.Merger(cfg), O.Refiner(cfg)]
+    for n in nets:
+        n.apply(O.init_weights)
+        n.train()
+    g = torch.Generator().manual_seed(0)
+    x = (0.5 * torch.randn(1, views, 3, 224, 224, generator=g)).clamp(-1, 1)
+    gt = (torch.rand(1, 32, 32, 32, generator=g) < 0.1).float()
+    t0 = time.time()
+    total, *_ = O.train_step_loss(nets, cfg, x, gt)
+    total.backward()
+    dt = time.time() - t0
+    return {"value": views / dt, "unit": "views/s", "cores": threads, "kind": "port",
+            "sample": f"1 fwd+bwd step, B=1 x V={views} views 224x224, fp32 torch CPU oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--math", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-views", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import swinvox_amd as S
+    from swinvox_amd import hip
+    from swinvox_amd.dp import GradAllReducer
+    from swinvox_amd.models import Decoder, Encoder, Merger, Refiner
+    import oracle as O   # only for init_weights-equivalent recipe below and the cpu_baseline leg
+
+    hip.load()
+    S.set_math(args.math)
+    torch.manual_seed(1234 + rank)
+    cfg = S.default_cfg()
+    nets = [Encoder(cfg), Decoder(cfg), Merger(cfg), Refiner(cfg)]
+    for n in nets:
+        n.apply(O.init_weights)          # reference weight recipe (utils/helpers.py:20-44); values do not affect speed
+        n.to(dev).train()
+    reducer = GradAllReducer([nets[3], nets[2], nets[1], nets[0]]) if world > 1 else None
+
+    B, V = args.batch, args.views
+    g = torch.Generator().manual_seed(rank)
+    images = (0.5 * torch.randn(B, V, 3, 224, 224, generator=g)).clamp(-1, 1).to(dev)
+    gt = (torch.rand(B, 32, 32, 32, generator=g) < 0.10).float().to(dev)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+
+    def step():
+        for n in nets:
+            for p in n.parameters():
+                p.grad = None
+        raw, vol = nets[1](nets[0](images))
+        merged = nets[2](raw, vol)
+        refined = nets[3](merged)
+        total = bce(merged, gt) + bce(refined, gt)
+        total.backward()
+        if reducer is not None:
+            reducer.finish()
+        return total
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    tracer = hip.Tracer({"sv_conv_gather", "sv_tconv_gather", "sv_conv_wgrad", "sv_window_attention_fwd", "sv_window_attention_bwd"})
+    hip.TRACE = tracer if rank == 0 else None
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    hip.TRACE = None
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    assert bool(torch.isfinite(loss)), "non-finite loss"
+
+    if rank == 0:
+        views_total = world * B * V * args.steps
+        value = views_total / dt
+        summ = tracer.summary()
+        # dominant kernel family = the contraction engine (sv_conv_gather + sv_tconv_gather + sv_conv_wgrad)
+        eng = [summ[k] for k in ("sv_conv_gather", "sv_tconv_gather", "sv_conv_wgrad") if k in summ]
+        eng_ms = sum(d["ms"] for d in eng)
+        eng_fl = sum(d["flops"] for d in eng)
+        eng_n = sum(d["launches"] for d in eng)
+        achieved = eng_fl / (eng_ms * 1e-3) / 1e12 if eng_ms > 0 else 0.0
+        peak = PEAK_TFLOPS[args.math]
+        out = {
+            "metric": "views/sec fwd+bwd SwinVox-T 224^2, 32^3 voxel, n_views=8", "value": value, "unit": "views/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.math == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"SwinVox-T full pipeline (ResNet50[:layer3] || Swin-T multi-stage, cross-view attention, "
+                                   f"decoder, merger, refiner), fwd+2xBCE+bwd, train mode, B={B} samples x V={V} views of 224x224 per GPU",
+                       "global_batch": world * B, "n_views": V, "images_per_gpu": B * V,
+                       "parallelism": f"dp{world} (sample-sharded, RCCL gradient all-reduce)" if world > 1 else "single GPU",
+                       "math": "bf16 MFMA inputs, fp32 accumulate, fp32 activations/weights in HBM" if args.math == "bf16" else "exact fp32 MFMA"},
+            "roofline": {"bound": "mfma", "kernel": "implicit-GEMM contraction engine (igemm_kernel / wgrad_kernel: all Linear/Conv/ConvTranspose fwd+dgrad+wgrad)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "launches_per_step": eng_n / args.steps, "avg_launch_us": eng_ms * 1e3 / max(eng_n, 1),
+                         "share_of_step_time": eng_ms * 1e-3 / dt},
+            "kernels": {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["ms"] / args.steps,
+                            "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None}
+                        for k, v in summ.items()},
+            "model_flops_tflops_per_gpu": 3 * FWD_GFLOP_PER_VIEW.get(V, 19.4) * 1e9 * value / world / 1e12,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_views, os.cpu_count() or 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

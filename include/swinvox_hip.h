@@ -62,7 +62,7 @@ typedef struct sv_epilogue {
   const float* row_scale; /* optional per-image scale of val before the residual add (drop-path), index = row / rows_per_scale */
   int rows_per_scale;
   float* pre_act;        /* optional: receives val (after bias, before activation), same layout as out */
-  float* stats;          /* optional [2*Co]: atomically accumulates sum and sum-of-squares of the stored output per channel */
+  double* stats;         /* optional [2*Co] DOUBLES: atomically accumulates sum and sum-of-squares of the stored output per channel */
   int act;               /* SV_ACT_* applied to val (after bias) */
   float slope;           /* LeakyReLU slope */
   const float* act_grad_src; /* optional: val *= act'(act_grad_src[pos]) (backward through an activation), layout of out */
@@ -106,15 +106,15 @@ int sv_ln_image_fwd(const float* x, const float* w, const float* b, float* y, fl
                     int I, int L, float eps, float drop_p, uint32_t seed, void* stream);
 int sv_ln_image_bwd(const float* dy, const float* x, const float* w, const float* meanrstd, float* dx, float* dw,
                     float* db, float* sums_ws, int I, int L, float drop_p, uint32_t seed, void* stream);
-int sv_bn_stats(const float* x, long long M, int C, int ld, float* sums, void* stream);
-int sv_bn_finalize(const float* sums, long long count, const float* gamma, const float* beta, float* running_mean,
+int sv_bn_stats(const float* x, long long M, int C, int ld, double* sums, void* stream);   /* sums: [2*C] doubles */
+int sv_bn_finalize(const double* sums, long long count, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float momentum, float eps, int training, float* scale, float* shift,
                    float* save_mean, float* save_rstd, int C, void* stream);
 int sv_scale_shift_act(const float* x, int ldx, const float* scale, const float* shift, const float* residual, int ldr,
                        float* y, int ldy, long long M, int C, int act, float slope, void* stream);
 int sv_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const float* x, int ldx, const float* gamma,
               const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
-              float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta, float* sums_ws, void* stream);
+              float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws /* [2*C] doubles */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention cores.  Window attention = timm WindowAttention + SwinTransformerBlock roll/partition/mask

@@ -3,28 +3,29 @@
 // One kernel family serves every Linear / Conv2d / Conv3d / ConvTranspose3d of the SwinVox path:
 //   igemm_kernel<BF16, TCONV>  out[row, co] = epilogue( sum_k A[row, k] * W[co, k] )
 //       A is never materialised: k = (tap, ci) is decoded to a gathered input position on the fly
-//       (channels-last activations, so the ci run of one tap is contiguous -> 16-byte loads).
-//       TCONV = stride-s transposed gather, decomposed into s^3 output parity classes (blockIdx.z) so
-//       that only taps that really contribute are visited.
+//       (channels-last activations, so the ci run of one tap is contiguous -> 16-byte loads).  The tap
+//       coordinates of a thread's k-chunk advance incrementally from K-step to K-step (no integer division
+//       in the main loop).  TCONV = stride-s transposed gather, decomposed into s^3 output parity classes
+//       (blockIdx.z) so that only taps that really contribute are visited.
 //   wgrad_kernel<BF16>         dw[ca, cg, tap] += sum_r anchor[r, ca] * gathered[pos(r, tap), cg]
 //       reduction over positions, split across blockIdx.z, fp32 atomics into the native weight layout.
-// Tiles: 128x64 outputs per 256-thread workgroup (4 waves as 2x2, each 64x32 = 4x2 MFMA tiles), K-step 32,
-// global->register prefetch of tile k+1 under the MFMAs of tile k (register-staged: the gather needs
-// per-element predication, which LDS-DMA cannot express).
+// Tiles: 128x64 outputs per 256-thread workgroup (4 waves as 2x2, each 64x32 = 4x2 MFMA tiles); K-step 32 (fp32)
+// or 64 (bf16); global->register prefetch of step k+1 under the MFMAs of step k (register-staged: the gather
+// needs per-element predication and an fp32->bf16 conversion, which LDS-DMA cannot express).
 #include "common.h"
 
 namespace sv {
 
-constexpr int BM = 128, BN = 64, BK = 32;
+constexpr int BM = 128, BN = 64;
 constexpr int PAD_F32 = 4;   // floats  -> row stride 36 floats (144 B, 16-B aligned)
-constexpr int PAD_BF16 = 8;  // bf16    -> row stride 40 bf16 (80 B, 16-B aligned)
+constexpr int PAD_BF16 = 8;  // bf16    -> row stride 72 bf16 (144 B, 16-B aligned)
 
 struct Geom {
   int N, Di, Hi, Wi, Do, Ho, Wo, Ci, Co, kd, kh, kw, sd, sh, sw, pd, ph, pw, ldi;
 };
 struct Epi {
   const float* bias; const float* residual; int ldr; const float* row_scale; int rows_per_scale;
-  float* pre_act; float* stats; int act; float slope; const float* act_grad_src; int act_grad_kind; int ldc; int col_off;
+  float* pre_act; double* stats; int act; float slope; const float* act_grad_src; int act_grad_kind; int ldc; int col_off;
 };
 struct ClassInfo {  // one output parity class of a transposed gather
   int o0[3];        // first output index of the class per axis
@@ -40,8 +41,12 @@ struct IGemmArgs {
   ClassInfo cls[8];
 };
 
-template <bool BF16> struct LdsT { typedef float T; static constexpr int PAD = PAD_F32; };
-template <> struct LdsT<true> { typedef __bf16 T; static constexpr int PAD = PAD_BF16; };
+template <bool BF16> struct Cfg {
+  typedef float T; static constexpr int BK = 32; static constexpr int PAD = PAD_F32;
+};
+template <> struct Cfg<true> {
+  typedef __bf16 T; static constexpr int BK = 64; static constexpr int PAD = PAD_BF16;
+};
 
 __device__ __forceinline__ void store4(float* dst, float4 v) { *reinterpret_cast<float4*>(dst) = v; }
 __device__ __forceinline__ void store4(__bf16* dst, float4 v) {
@@ -52,22 +57,25 @@ __device__ __forceinline__ void store4(__bf16* dst, float4 v) {
 __device__ __forceinline__ void store1(float* dst, float v) { *dst = v; }
 __device__ __forceinline__ void store1(__bf16* dst, float v) { *dst = (__bf16)v; }
 
-// acc[4][2] += A(64 rows of this wave) x B(32 cols of this wave) over one BK=32 slab in LDS
+// acc[4][2] += A(64 rows of this wave) x B(32 cols of this wave) over one K-step slab in LDS
 template <bool BF16>
-__device__ __forceinline__ void mma_slab(const typename LdsT<BF16>::T* As, const typename LdsT<BF16>::T* Bs,
+__device__ __forceinline__ void mma_slab(const typename Cfg<BF16>::T* As, const typename Cfg<BF16>::T* Bs,
                                          int wm, int wn, int lane, f32x4 (&acc)[4][2]) {
-  constexpr int LD = BK + LdsT<BF16>::PAD;
+  constexpr int BK = Cfg<BF16>::BK, LD = BK + Cfg<BF16>::PAD;
   const int lr = lane & 15, lg = lane >> 4;
   if constexpr (BF16) {
-    bf16x8 a[4], b[2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(As + (wm * 64 + mt * 16 + lr) * LD + lg * 8);
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 a[4], b[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(Bs + (wn * 32 + nt * 16 + lr) * LD + lg * 8);
+      for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(As + (wm * 64 + mt * 16 + lr) * LD + ks * 32 + lg * 8);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+      for (int nt = 0; nt < 2; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(Bs + (wn * 32 + nt * 16 + lr) * LD + ks * 32 + lg * 8);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
   } else {
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
@@ -84,13 +92,24 @@ __device__ __forceinline__ void mma_slab(const typename LdsT<BF16>::T* As, const
   }
 }
 
+// row index -> (n, d, h, w) of a grid; spatial == 1 (Linear) needs no division at all
+__device__ __forceinline__ void decode_row(int m, int c0, int c1, int c2, int& n_, int& d_, int& h_, int& w_) {
+  if (c0 * c1 * c2 == 1) { n_ = m; d_ = h_ = w_ = 0; return; }
+  w_ = m % c2; int t = m / c2;
+  h_ = t % c1; t /= c1;
+  d_ = t % c0; n_ = t / c0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------------
 template <bool BF16, bool TCONV>
 __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
-  typedef typename LdsT<BF16>::T LT;
-  constexpr int LD = BK + LdsT<BF16>::PAD;
+  typedef typename Cfg<BF16>::T LT;
+  constexpr int BK = Cfg<BF16>::BK, LD = BK + Cfg<BF16>::PAD;
+  constexpr int TPR = BK / 4;          // threads per tile row (one float4 each)
+  constexpr int RPP = 256 / TPR;       // rows per pass
+  constexpr int NA = BM / RPP, NB = BN / RPP;
   __shared__ __attribute__((aligned(16))) LT As[BM * LD];
   __shared__ __attribute__((aligned(16))) LT Bs[BN * LD];
 
@@ -98,7 +117,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // class setup (TCONV) or the single dense "class"
   int cnt0, cnt1, cnt2, T0, T1, T2;
   ClassInfo ci;
   if constexpr (TCONV) {
@@ -109,92 +127,105 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
     cnt0 = g.Do; cnt1 = g.Ho; cnt2 = g.Wo;
     T0 = g.kd; T1 = g.kh; T2 = g.kw;
   }
-  const long long Mrows = (long long)g.N * cnt0 * cnt1 * cnt2;
+  const int Mrows = g.N * cnt0 * cnt1 * cnt2;
   const int K = T0 * T1 * T2 * g.Ci;
-  const long long row0 = (long long)blockIdx.x * BM;
+  const int row0 = blockIdx.x * BM;
   if (row0 >= Mrows) return;
   const int col0 = blockIdx.y * BN;
 
-  // ---- per-thread loader state: 4 A rows + 2 B rows, one fixed 4-wide k chunk -----------------
-  const int kq = (tid & 7) * 4;
-  const int rb = tid >> 3;  // 0..31
-  int a_n[4], a_d[4], a_h[4], a_w[4];
-  bool a_ok[4];
+  // ---- per-thread loader state -----------------------------------------------------------------
+  const int kq = (tid % TPR) * 4;
+  const int rb = tid / TPR;
+  int a_n[NA], a_d[NA], a_h[NA], a_w[NA];
+  bool a_ok[NA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    long long m = row0 + rb + 32 * i;
+  for (int i = 0; i < NA; ++i) {
+    int m = row0 + rb + RPP * i;
     a_ok[i] = m < Mrows;
     if (!a_ok[i]) m = 0;
-    int w_ = (int)(m % cnt2); long long t = m / cnt2;
-    int h_ = (int)(t % cnt1); t /= cnt1;
-    int d_ = (int)(t % cnt0); int n_ = (int)(t / cnt0);
+    int n_, d_, h_, w_;
+    decode_row(m, cnt0, cnt1, cnt2, n_, d_, h_, w_);
     a_n[i] = n_;
-    if constexpr (TCONV) {  // gathered index for tap t: ib0 + j - t
-      a_d[i] = ci.ib0[0] + d_; a_h[i] = ci.ib0[1] + h_; a_w[i] = ci.ib0[2] + w_;
-    } else {                // gathered index for tap t: o*s - p + t
-      a_d[i] = d_ * g.sd - g.pd; a_h[i] = h_ * g.sh - g.ph; a_w[i] = w_ * g.sw - g.pw;
-    }
+    if constexpr (TCONV) { a_d[i] = ci.ib0[0] + d_; a_h[i] = ci.ib0[1] + h_; a_w[i] = ci.ib0[2] + w_; }   // gathered idx = this - t
+    else { a_d[i] = d_ * g.sd - g.pd; a_h[i] = h_ * g.sh - g.ph; a_w[i] = w_ * g.sw - g.pw; }              // gathered idx = this + t
   }
   const bool vec_ok = (g.Ci & 3) == 0 && (g.ldi & 3) == 0;
+  // running tap state of this thread's k-chunk (vector path): channel offset kc inside the tap, tap coords
+  int kc = 0, tw = 0, th = 0, td = 0, kcur = kq;
+  if (vec_ok && K > 0) {
+    const int tap = kq / g.Ci;
+    kc = kq - tap * g.Ci;
+    tw = tap % T2; const int t2 = tap / T2; th = t2 % T1; td = t2 / T1;
+  }
 
-  float4 ra[4], rbv[2];
-  auto load_tile = [&](int kt) {
-    const int k = kt * BK + kq;
-    // ---- A (gathered activations)
+  float4 ra[NA], rbv[NB];
+  auto load_tile = [&]() {   // loads the tile at the running k position, then advances the state by BK
     if (vec_ok) {
-      int tap = k / g.Ci, c = k - tap * g.Ci;
-      int tw = tap % T2; int t2 = tap / T2; int th = t2 % T1; int td = t2 / T1;
-      const bool kok = k < K;
+      const bool kok = td < T0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NA; ++i) {
         int id, ih, iw;
         if constexpr (TCONV) { id = a_d[i] - td; ih = a_h[i] - th; iw = a_w[i] - tw; }
         else { id = a_d[i] + td; ih = a_h[i] + th; iw = a_w[i] + tw; }
         const bool ok = kok && a_ok[i] && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi;
         if (ok) {
-          const size_t off = ((((size_t)a_n[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + c;
+          const size_t off = ((((size_t)a_n[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + kc;
           ra[i] = *reinterpret_cast<const float4*>(p.x + off);
         } else {
           ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
-    } else {  // scalar path: any Ci (stem Ci=3, refiner head Ci=1 ...)
+      // weights: [Co][taps_total][Ci]; TCONV maps the class-local tap to its kernel index
+      size_t woff;
+      if constexpr (TCONV) {
+        const int kd_ = ci.r[0] + g.sd * td, kh_ = ci.r[1] + g.sh * th, kw_ = ci.r[2] + g.sw * tw;
+        woff = (size_t)((kd_ * g.kh + kh_) * g.kw + kw_) * g.Ci + kc;
+      } else {
+        woff = (size_t)kcur;
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NB; ++i) {
+        const int n = col0 + rb + RPP * i;
+        if (n < g.Co && kok) rbv[i] = *reinterpret_cast<const float4*>(p.w + (size_t)n * p.Ktot + woff);
+        else rbv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      // advance
+      kcur += BK; kc += BK;
+      while (kc >= g.Ci) {
+        kc -= g.Ci;
+        if (++tw == T2) { tw = 0; if (++th == T1) { th = 0; ++td; } }
+      }
+    } else {  // scalar path: any Ci (stem Ci=3, refiner head Ci=1 ...), per-element tap decode
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int kk = k + j;
-          int tap = kk / g.Ci, c = kk - tap * g.Ci;
-          int tw = tap % T2; int t2 = tap / T2; int th = t2 % T1; int td = t2 / T1;
+          const int kk = kcur + j;
+          const int tap = kk / g.Ci, c = kk - tap * g.Ci;
+          const int tw_ = tap % T2; const int t2 = tap / T2; const int th_ = t2 % T1; const int td_ = t2 / T1;
           int id, ih, iw;
-          if constexpr (TCONV) { id = a_d[i] - td; ih = a_h[i] - th; iw = a_w[i] - tw; }
-          else { id = a_d[i] + td; ih = a_h[i] + th; iw = a_w[i] + tw; }
+          if constexpr (TCONV) { id = a_d[i] - td_; ih = a_h[i] - th_; iw = a_w[i] - tw_; }
+          else { id = a_d[i] + td_; ih = a_h[i] + th_; iw = a_w[i] + tw_; }
           const bool ok = kk < K && a_ok[i] && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi;
           v[j] = ok ? p.x[((((size_t)a_n[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + c] : 0.f;
         }
         ra[i] = make_float4(v[0], v[1], v[2], v[3]);
       }
-    }
-    // ---- B (packed weights [Co][taps_total][Ci]); TCONV maps class-local taps to kernel indices
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int n = col0 + rb + 32 * i;
-      float v[4];
-      if (!TCONV && vec_ok) {
-        if (n < g.Co && k < K) rbv[i] = *reinterpret_cast<const float4*>(p.w + (size_t)n * p.Ktot + k);
-        else rbv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
+      for (int i = 0; i < NB; ++i) {
+        const int n = col0 + rb + RPP * i;
+        float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int kk = k + j;
+          const int kk = kcur + j;
           float val = 0.f;
           if (n < g.Co && kk < K) {
             int kidx = kk;
             if constexpr (TCONV) {
-              int tap = kk / g.Ci, c = kk - tap * g.Ci;
-              int tw = tap % T2; int t2 = tap / T2; int th = t2 % T1; int td = t2 / T1;
-              const int kd_ = ci.r[0] + g.sd * td, kh_ = ci.r[1] + g.sh * th, kw_ = ci.r[2] + g.sw * tw;
+              const int tap = kk / g.Ci, c = kk - tap * g.Ci;
+              const int tw_ = tap % T2; const int t2 = tap / T2; const int th_ = t2 % T1; const int td_ = t2 / T1;
+              const int kd_ = ci.r[0] + g.sd * td_, kh_ = ci.r[1] + g.sh * th_, kw_ = ci.r[2] + g.sw * tw_;
               kidx = ((kd_ * g.kh + kh_) * g.kw + kw_) * g.Ci + c;
             }
             val = p.w[(size_t)n * p.Ktot + kidx];
@@ -203,13 +234,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
         }
         rbv[i] = make_float4(v[0], v[1], v[2], v[3]);
       }
+      kcur += BK;
     }
   };
   auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) store4(As + (rb + 32 * i) * LD + kq, ra[i]);
+    for (int i = 0; i < NA; ++i) store4(As + (rb + RPP * i) * LD + kq, ra[i]);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) store4(Bs + (rb + 32 * i) * LD + kq, rbv[i]);
+    for (int i = 0; i < NB; ++i) store4(Bs + (rb + RPP * i) * LD + kq, rbv[i]);
   };
 
   f32x4 acc[4][2];
@@ -220,11 +252,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
 
   const int nk = (K + BK - 1) / BK;
   if (nk > 0) {
-    load_tile(0);
+    load_tile();
     store_tile();
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) load_tile(kt + 1);
+      if (kt + 1 < nk) load_tile();
       mma_slab<BF16>(As, Bs, wm, wn, lane, acc);
       __syncthreads();
       if (kt + 1 < nk) {
@@ -237,6 +269,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
   // ---- epilogue: C tile element (row = (lane>>4)*4 + j, col = lane&15) ---------------------------
   const Epi& e = p.e;
   const int lr = lane & 15, lg = lane >> 4;
+  int pos[4][4];   // output position (pixel index) of this lane's 16 rows, -1 = out of range
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = row0 + wm * 64 + mt * 16 + lg * 4 + j;
+      int ps = -1;
+      if (m < Mrows) {
+        if constexpr (TCONV) {
+          int n_, d_, h_, w_;
+          decode_row(m, cnt0, cnt1, cnt2, n_, d_, h_, w_);
+          const int od = ci.o0[0] + g.sd * d_, oh = ci.o0[1] + g.sh * h_, ow = ci.o0[2] + g.sw * w_;
+          ps = ((n_ * g.Do + od) * g.Ho + oh) * g.Wo + ow;
+        } else {
+          ps = m;
+        }
+      }
+      pos[mt][j] = ps;
+    }
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int n = col0 + wn * 32 + nt * 16 + lr;
@@ -247,27 +298,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
     for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const long long m = row0 + wm * 64 + mt * 16 + lg * 4 + j;
-        if (m < Mrows && nok) {
-          size_t pos;  // output position index (pixel) in the produced tensor
-          if constexpr (TCONV) {
-            int w_ = (int)(m % cnt2); long long t = m / cnt2;
-            int h_ = (int)(t % cnt1); t /= cnt1;
-            int d_ = (int)(t % cnt0); int n_ = (int)(t / cnt0);
-            const int od = ci.o0[0] + g.sd * d_, oh = ci.o0[1] + g.sh * h_, ow = ci.o0[2] + g.sw * w_;
-            pos = (((size_t)n_ * g.Do + od) * g.Ho + oh) * g.Wo + ow;
-          } else {
-            pos = (size_t)m;
-          }
+        const int ps = pos[mt][j];
+        if (ps >= 0 && nok) {
+          const size_t o = (size_t)ps * e.ldc + e.col_off + n;
           float v = acc[mt][nt][j] + bias;
-          if (e.act_grad_src) v *= act_grad(e.act_grad_src[pos * e.ldc + e.col_off + n], e.act_grad_kind, e.slope);
-          if (e.pre_act) e.pre_act[pos * e.ldc + e.col_off + n] = v;
+          if (e.act_grad_src) v *= act_grad(e.act_grad_src[o], e.act_grad_kind, e.slope);
+          if (e.pre_act) e.pre_act[o] = v;
           v = apply_act(v, e.act, e.slope);
           if (e.residual) {
-            const float sc = e.row_scale ? e.row_scale[pos / e.rows_per_scale] : 1.f;
-            v = e.residual[pos * e.ldr + n] + sc * v;
+            const float sc = e.row_scale ? e.row_scale[ps / e.rows_per_scale] : 1.f;
+            v = e.residual[(size_t)ps * e.ldr + n] + sc * v;
           }
-          p.y[pos * e.ldc + e.col_off + n] = v;
+          p.y[o] = v;
           s1 += v; s2 += v * v;
         }
       }
@@ -276,8 +318,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
       s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
       if (lg == 0 && nok) {
-        atomicAdd(e.stats + n, s1);
-        atomicAdd(e.stats + g.Co + n, s2);
+        atomicAdd(e.stats + n, (double)s1);
+        atomicAdd(e.stats + g.Co + n, (double)s2);
       }
     }
   }
@@ -288,13 +330,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
 // ------------------------------------------------------------------------------------------------
 struct WGradArgs {
   const float* anchor; int lda; const float* gathered; float* dw;
-  Geom g; int cg_valid; long long rows_per_split; long long Mrows;
+  Geom g; int cg_valid; int rows_per_split; int Mrows;
 };
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs p) {
-  typedef typename LdsT<BF16>::T LT;
-  constexpr int LD = BK + LdsT<BF16>::PAD;
+  typedef typename Cfg<BF16>::T LT;
+  constexpr int BK = Cfg<BF16>::BK, LD = BK + Cfg<BF16>::PAD;
+  constexpr int NAR = BK / 8;    // A: 32 threads span 128 ca (float4 each) -> 8 rows per pass
+  constexpr int NBR = BK / 16;   // B: 16 threads span 64 k_out            -> 16 rows per pass
   __shared__ __attribute__((aligned(16))) LT As[BM * LD];  // [ca][r]
   __shared__ __attribute__((aligned(16))) LT Bs[BN * LD];  // [k_out][r]
 
@@ -304,27 +348,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs p) {
   const int taps = g.kd * g.kh * g.kw;
   const int Kout = taps * g.Ci;
   const int ca0 = blockIdx.x * BM, ko0 = blockIdx.y * BN;
-  const long long r_begin = (long long)blockIdx.z * p.rows_per_split;
-  long long r_end = r_begin + p.rows_per_split;
+  const int r_begin = blockIdx.z * p.rows_per_split;
+  int r_end = r_begin + p.rows_per_split;
   if (r_end > p.Mrows) r_end = p.Mrows;
   if (r_begin >= r_end) return;
 
-  // A loader: thread -> 4 consecutive ca, rows rr + 8*i (i<4)
   const int a_c = (tid & 31) * 4, a_r = tid >> 5;
-  // B loader: thread -> 4 consecutive k_out (one tap, 4 cg), rows rr + 16*i (i<2)
   const int b_k = ko0 + (tid & 15) * 4, b_r = tid >> 4;
   const bool avec = (p.lda & 3) == 0, bvec = (g.Ci & 3) == 0 && (g.ldi & 3) == 0;
-  int b_tap = 0, b_c = 0, b_td = 0, b_th = 0, b_tw = 0;
+  const bool dense = (g.Do * g.Ho * g.Wo == 1) && taps == 1;   // Linear: gathered row == anchor row
+  int b_c = 0, b_td = 0, b_th = 0, b_tw = 0;
   if (bvec) {
-    b_tap = b_k / g.Ci; b_c = b_k - b_tap * g.Ci;
-    b_tw = b_tap % g.kw; int t2 = b_tap / g.kw; b_th = t2 % g.kh; b_td = t2 / g.kh;
+    const int b_tap = b_k / g.Ci; b_c = b_k - b_tap * g.Ci;
+    b_tw = b_tap % g.kw; const int t2 = b_tap / g.kw; b_th = t2 % g.kh; b_td = t2 / g.kh;
   }
-
-  float4 ra[4], rbv[2];
-  auto load_tile = [&](long long r0) {
+  // running (n,d,h,w) of the rows this thread gathers for B; advanced by BK per step without division
+  int bn_[NBR], bd_[NBR], bh_[NBR], bw_[NBR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long long r = r0 + a_r + 8 * i;
+  for (int i = 0; i < NBR; ++i) decode_row(r_begin + b_r + 16 * i, g.Do, g.Ho, g.Wo, bn_[i], bd_[i], bh_[i], bw_[i]);
+
+  float4 ra[NAR], rbv[NBR];
+  int r0 = r_begin;
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NAR; ++i) {
+      const int r = r0 + a_r + 8 * i;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (r < r_end) {
         const float* src = p.anchor + (size_t)r * p.lda + ca0 + a_c;
@@ -339,47 +387,68 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs p) {
       ra[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const long long r = r0 + b_r + 16 * i;
+    for (int i = 0; i < NBR; ++i) {
+      const int r = r0 + b_r + 16 * i;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (r < r_end) {
-        int w_ = (int)(r % g.Wo); long long t = r / g.Wo;
-        int h_ = (int)(t % g.Ho); t /= g.Ho;
-        int d_ = (int)(t % g.Do); int n_ = (int)(t / g.Do);
-        const int bd = d_ * g.sd - g.pd, bh = h_ * g.sh - g.ph, bw = w_ * g.sw - g.pw;
-        if (bvec) {
-          const int id = bd + b_td, ih = bh + b_th, iw = bw + b_tw;
-          if (b_k < Kout && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi) {
-            const float4 q = *reinterpret_cast<const float4*>(
-                p.gathered + ((((size_t)n_ * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + b_c);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        if (dense) {
+          if (bvec) {
+            if (b_k < Kout) {
+              const float4 q = *reinterpret_cast<const float4*>(p.gathered + (size_t)r * g.ldi + b_k);
+              v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (b_k + j < Kout) v[j] = p.gathered[(size_t)r * g.ldi + b_k + j];
           }
         } else {
+          const int bd = bd_[i] * g.sd - g.pd, bh = bh_[i] * g.sh - g.ph, bw = bw_[i] * g.sw - g.pw;
+          if (bvec) {
+            const int id = bd + b_td, ih = bh + b_th, iw = bw + b_tw;
+            if (b_k < Kout && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi) {
+              const float4 q = *reinterpret_cast<const float4*>(
+                  p.gathered + ((((size_t)bn_[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + b_c);
+              v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            }
+          } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int kk = b_k + j;
-            if (kk < Kout) {
-              int tap = kk / g.Ci, c = kk - tap * g.Ci;
-              int tw = tap % g.kw; int t2 = tap / g.kw; int th = t2 % g.kh; int td = t2 / g.kh;
-              const int id = bd + td, ih = bh + th, iw = bw + tw;
-              if ((unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi)
-                v[j] = p.gathered[((((size_t)n_ * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + c];
+            for (int j = 0; j < 4; ++j) {
+              const int kk = b_k + j;
+              if (kk < Kout) {
+                const int tap = kk / g.Ci, c = kk - tap * g.Ci;
+                const int tw = tap % g.kw; const int t2 = tap / g.kw; const int th = t2 % g.kh; const int td = t2 / g.kh;
+                const int id = bd + td, ih = bh + th, iw = bw + tw;
+                if ((unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi)
+                  v[j] = p.gathered[((((size_t)bn_[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + c];
+              }
             }
           }
         }
       }
       rbv[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
+    // advance the running row coordinates by BK
+    r0 += BK;
+    if (!dense) {
+#pragma unroll
+      for (int i = 0; i < NBR; ++i) {
+        bw_[i] += BK;
+        while (bw_[i] >= g.Wo) {
+          bw_[i] -= g.Wo;
+          if (++bh_[i] == g.Ho) { bh_[i] = 0; if (++bd_[i] == g.Do) { bd_[i] = 0; ++bn_[i]; } }
+        }
+      }
+    }
   };
   auto store_tile = [&]() {  // transposing stores: reduction index r becomes the contiguous LDS dimension
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NAR; ++i) {
       const int r = a_r + 8 * i;
       store1(As + (a_c + 0) * LD + r, ra[i].x); store1(As + (a_c + 1) * LD + r, ra[i].y);
       store1(As + (a_c + 2) * LD + r, ra[i].z); store1(As + (a_c + 3) * LD + r, ra[i].w);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NBR; ++i) {
       const int r = b_r + 16 * i;
       const int kl = (tid & 15) * 4;
       store1(Bs + (kl + 0) * LD + r, rbv[i].x); store1(Bs + (kl + 1) * LD + r, rbv[i].y);
@@ -393,12 +462,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs p) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  load_tile(r_begin);
+  load_tile();
   store_tile();
   __syncthreads();
-  for (long long r0 = r_begin; r0 < r_end; r0 += BK) {
-    const bool more = r0 + BK < r_end;
-    if (more) load_tile(r0 + BK);
+  for (int rr = r_begin; rr < r_end; rr += BK) {
+    const bool more = rr + BK < r_end;
+    if (more) load_tile();
     mma_slab<BF16>(As, Bs, wm, wn, lane, acc);
     __syncthreads();
     if (more) {
@@ -476,6 +545,8 @@ static int check_common(const sv_geom* g, const sv_epilogue* e, const void* in, 
   SV_REQUIRE(e->ldc >= e->col_off + g->Co, "igemm: ldc (%d) < col_off+Co (%d)", e->ldc, e->col_off + g->Co);
   SV_REQUIRE(!e->residual || e->ldr >= g->Co, "igemm: ldr (%d) < Co (%d)", e->ldr, g->Co);
   SV_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)w & 15) == 0, "igemm: in/w must be 16-byte aligned");
+  SV_REQUIRE((long long)g->N * g->Do * g->Ho * g->Wo < (1ll << 31) && (long long)g->N * g->Di * g->Hi * g->Wi < (1ll << 31),
+             "igemm: more than 2^31 positions");
   return SV_OK;
 }
 
@@ -539,21 +610,24 @@ extern "C" int sv_conv_wgrad(const float* anchor, int lda, const float* gathered
   SV_REQUIRE(lda >= g->Co && g->ldi >= g->Ci && cg_valid > 0 && cg_valid <= g->Ci, "wgrad: bad strides (lda=%d Co=%d ldi=%d Ci=%d cg_valid=%d)",
              lda, g->Co, g->ldi, g->Ci, cg_valid);
   SV_REQUIRE(((uintptr_t)anchor & 15) == 0 && ((uintptr_t)gathered & 15) == 0, "wgrad: operands must be 16-byte aligned");
+  const long long Mll = (long long)g->N * g->Do * g->Ho * g->Wo;
+  SV_REQUIRE(Mll > 0 && Mll < (1ll << 31), "wgrad: row count out of range");
   WGradArgs a{};
   a.anchor = anchor; a.lda = lda; a.gathered = gathered; a.dw = dw; a.g = to_geom(g); a.cg_valid = cg_valid;
-  a.Mrows = (long long)g->N * g->Do * g->Ho * g->Wo;
+  a.Mrows = (int)Mll;
+  const int BKs = math == SV_MATH_BF16 ? 64 : 32;
   const int Kout = g->kd * g->kh * g->kw * g->Ci;
   const int tiles = cdiv(g->Co, BM) * cdiv(Kout, BN);
-  // enough splits to fill ~4 waves of workgroups per CU, but at least 4 K-steps of work per split
+  // enough splits to fill ~4 workgroups per CU, but at least 4 K-steps of work per split
   long long splits = (1024 + tiles - 1) / tiles;
-  const long long max_splits = (a.Mrows + 4 * BK - 1) / (4 * BK);
+  const long long max_splits = (Mll + 4 * BKs - 1) / (4 * BKs);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (splits > 65535) splits = 65535;
-  long long rps = (a.Mrows + splits - 1) / splits;
-  rps = (rps + BK - 1) / BK * BK;
-  splits = (a.Mrows + rps - 1) / rps;
-  a.rows_per_split = rps;
+  long long rps = (Mll + splits - 1) / splits;
+  rps = (rps + BKs - 1) / BKs * BKs;
+  splits = (Mll + rps - 1) / rps;
+  a.rows_per_split = (int)rps;
   dim3 grid(cdiv(g->Co, BM), cdiv(Kout, BN), (unsigned)splits);
   hipStream_t s = (hipStream_t)stream;
   if (math == SV_MATH_BF16) hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, a);
@@ -575,7 +649,7 @@ extern "C" int sv_pack_weight(const float* src, float* dst, int A, int B, int T,
 extern "C" int sv_colsum(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* stream) {
   SV_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "colsum: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate) hipMemsetAsync(out, 0, sizeof(float) * cols, s);
+  if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * cols, s);
   const int cg = cdiv(cols, 64);
   int splits = 2048 / cg; if (splits < 1) splits = 1;
   const int maxs = cdiv(rows, 64); if (splits > maxs) splits = maxs;

@@ -281,13 +281,13 @@ __global__ __launch_bounds__(256) void lnl_bwd_apply_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 // per-channel sum and sum of squares (when the producing contraction did not accumulate them itself)
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long long M, int C, int ld,
-                                                       float* __restrict__ sums, long long rows_per_block) {
-  __shared__ float r1[4][64], r2[4][64];
+                                                       double* __restrict__ sums, long long rows_per_block) {
+  __shared__ double r1[4][64], r2[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const long long r0 = (long long)blockIdx.y * rows_per_block;
   long long r1e = r0 + rows_per_block; if (r1e > M) r1e = M;
-  float s1 = 0.f, s2 = 0.f;
-  if (c < C) for (long long r = r0 + rl; r < r1e; r += 4) { const float v = x[(size_t)r * ld + c]; s1 += v; s2 += v * v; }
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) for (long long r = r0 + rl; r < r1e; r += 4) { const double v = x[(size_t)r * ld + c]; s1 += v; s2 += v * v; }
   r1[rl][threadIdx.x & 63] = s1; r2[rl][threadIdx.x & 63] = s2;
   __syncthreads();
   if (rl == 0 && c < C) {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 
 // train: batch mean / biased var -> scale, shift, saved mean/rstd, running-stat update (unbiased var).
 // eval : scale/shift from the running statistics.
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, const float* __restrict__ gamma,
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float momentum, float eps, int training,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
@@ -306,11 +306,13 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, 
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float mean, var;
-  if (training) {
-    mean = sums[c] / count;
-    var = fmaxf(sums[C + c] / count - mean * mean, 0.f);
+  if (training) {   // statistics in double: E[x^2]-mean^2 cancels badly in fp32 (torch's CPU path accumulates in double too)
+    const double m = sums[c] / count;
+    double v = sums[C + c] / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m; var = (float)v;
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count > 1.f ? count / (count - 1.f) : 1.f);
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(v * (count > 1.0 ? count / (count - 1.0) : 1.0));
   } else {
     mean = running_mean[c]; var = running_var[c];
   }
@@ -358,18 +360,18 @@ __global__ __launch_bounds__(256) void scale_shift_act_scalar_kernel(const float
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz,
                                                             const float* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, long long M, int C, int act, float slope,
-                                                            float* __restrict__ sums, long long rows_per_block) {
-  __shared__ float r1[4][64], r2[4][64];
+                                                            double* __restrict__ sums, long long rows_per_block) {
+  __shared__ double r1[4][64], r2[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const long long r0 = (long long)blockIdx.y * rows_per_block;
   long long r1e = r0 + rows_per_block; if (r1e > M) r1e = M;
-  float s1 = 0.f, s2 = 0.f;
+  double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     const float mu = mean[c], rs = rstd[c];
     for (long long r = r0 + rl; r < r1e; r += 4) {
       float d = dz[(size_t)r * lddz + c];
       if (act != SV_ACT_NONE) d *= (z[(size_t)r * ldz + c] > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
-      s1 += d; s2 += d * (x[(size_t)r * ldx + c] - mu) * rs;
+      s1 += (double)d; s2 += (double)(d * (x[(size_t)r * ldx + c] - mu) * rs);
     }
   }
   r1[rl][threadIdx.x & 63] = s1; r2[rl][threadIdx.x & 63] = s2;
@@ -385,11 +387,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz,
                                                            const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ sums, long long M, int C, int act, float slope,
+                                                           const double* __restrict__ sums, long long M, int C, int act, float slope,
                                                            int training, float* __restrict__ dx, int lddx, float* __restrict__ dres,
                                                            int lddres, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const long long total = M * C;
-  const float invM = 1.f / (float)M;
+  const double invM = 1.0 / (double)M;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / C; const int c = (int)(i - r * C);
     float d = dz[(size_t)r * lddz + c];
@@ -399,14 +401,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     float o;
     if (training) {
       const float xh = (x[(size_t)r * ldx + c] - mean[c]) * rs;
-      o = gamma[c] * rs * (d - sums[c] * invM - xh * sums[C + c] * invM);
+      o = gamma[c] * rs * (d - (float)(sums[c] * invM) - xh * (float)(sums[C + c] * invM));
     } else {
       o = d * gamma[c] * rs;
     }
     dx[(size_t)r * lddx + c] = o;
   }
   if (blockIdx.x == 0)
-    for (int c = threadIdx.x; c < C; c += 256) { dgamma[c] += sums[C + c]; dbeta[c] += sums[c]; }
+    for (int c = threadIdx.x; c < C; c += 256) { dgamma[c] += (float)sums[C + c]; dbeta[c] += (float)sums[c]; }
 }
 
 }  // namespace sv
@@ -471,7 +473,7 @@ extern "C" int sv_ln_image_bwd(const float* dy, const float* x, const float* w, 
   return check_launch("sv_ln_image_bwd");
 }
 
-extern "C" int sv_bn_stats(const float* x, long long M, int C, int ld, float* sums, void* stream) {
+extern "C" int sv_bn_stats(const float* x, long long M, int C, int ld, double* sums, void* stream) {
   SV_REQUIRE(x && sums && M > 0 && C > 0 && ld >= C, "bn_stats: bad arguments");
   const int cg = cdiv(C, 64);
   long long splits = 2048 / cg; if (splits < 1) splits = 1;
@@ -481,12 +483,12 @@ extern "C" int sv_bn_stats(const float* x, long long M, int C, int ld, float* su
   return check_launch("sv_bn_stats");
 }
 
-extern "C" int sv_bn_finalize(const float* sums, long long count, const float* gamma, const float* beta, float* running_mean,
+extern "C" int sv_bn_finalize(const double* sums, long long count, const float* gamma, const float* beta, float* running_mean,
                               float* running_var, float momentum, float eps, int training, float* scale, float* shift,
                               float* save_mean, float* save_rstd, int C, void* stream) {
   SV_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && save_mean && save_rstd && C > 0, "bn_finalize: null argument");
   SV_REQUIRE(!training || (sums && count > 0), "bn_finalize: training needs sums and a positive count");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, (float)count, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, (double)count, gamma, beta,
                      running_mean, running_var, momentum, eps, training, scale, shift, save_mean, save_rstd, C);
   return check_launch("sv_bn_finalize");
 }
@@ -509,11 +511,11 @@ extern "C" int sv_scale_shift_act(const float* x, int ldx, const float* scale, c
 
 extern "C" int sv_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const float* x, int ldx, const float* gamma,
                          const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
-                         float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta, float* sums_ws, void* stream) {
+                         float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws, void* stream) {
   SV_REQUIRE(dz && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && sums_ws && M > 0 && C > 0, "bn_bwd: null/empty argument");
   SV_REQUIRE(act == SV_ACT_NONE || z, "bn_bwd: the activation mask needs the forward output z");
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(sums_ws, 0, sizeof(float) * 2 * C, s);
+  (void)hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * C, s);
   const int cg = cdiv(C, 64);
   long long splits = 2048 / cg; if (splits < 1) splits = 1;
   const long long maxs = (M + 63) / 64; if (splits > maxs) splits = maxs;

@@ -125,9 +125,50 @@ def check_cuda(*tensors) -> None:
                                f"device={t.device}")
 
 
+class Tracer:
+    """Times selected entry points with HIP events on the launch stream (bench.py's roofline leg).  Events are only
+    recorded, never waited for, inside the timed region; summary() synchronises afterwards."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []          # (name, start_event, end_event, algorithmic_flops, algorithmic_bytes)
+        self._open = None
+
+    def begin(self, name, flops=0.0, nbytes=0.0):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream())
+        self._open = (name, ev0, ev1, flops, nbytes)
+
+    def end(self):
+        name, ev0, ev1, flops, nbytes = self._open
+        ev1.record(torch.cuda.current_stream())
+        self.records.append(self._open)
+        self._open = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, ev0, ev1, flops, nbytes in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += ev0.elapsed_time(ev1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+TRACE = None   # set to a Tracer by bench.py
+
+
 def call(name: str, *args) -> None:
     """Invoke an entry point on the current torch stream; a non-zero return becomes a RuntimeError."""
     lib = load()
-    rc = getattr(lib, name)(*args, _stream())
+    tr = TRACE
+    if tr is not None and tr._open is None and name in tr.names:   # untimed-by-caller entry point selected for tracing
+        tr.begin(name)
+        rc = getattr(lib, name)(*args, _stream())
+        tr.end()
+    else:
+        rc = getattr(lib, name)(*args, _stream())
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib.sv_last_error().decode()}")

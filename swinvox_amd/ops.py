@@ -111,13 +111,31 @@ class ConvSpec:
     def _geom(self, n, gathered_grid, produced_grid, ci, co, ldi) -> Geom:
         return Geom(n, *gathered_grid, *produced_grid, ci, co, *self.k, *self.s, *self.p, ldi)
 
+    def _traced(self, name, n, in_grid, *args):
+        """Launch a contraction; when bench.py's tracer is active, bracket it with HIP events and book its ALGORITHMIC
+        work: 2 * positions * taps_that_contribute * cin * cout flops (no channel padding, no masked taps)."""
+        tr = hip.TRACE
+        if tr is None or name not in tr.names:
+            return call(name, *args)
+        og = self.out_grid(in_grid)
+        if self.transposed:   # every input position meets every tap exactly once
+            pairs = n * in_grid[0] * in_grid[1] * in_grid[2] * self.taps
+        else:                 # interior count; border taps falling into the padding are a small over-estimate (<3%)
+            pairs = n * og[0] * og[1] * og[2] * self.taps
+        flops = 2.0 * pairs * self.cin * self.cout
+        nin, nout = n * in_grid[0] * in_grid[1] * in_grid[2], n * og[0] * og[1] * og[2]
+        nbytes = 4.0 * (nin * self.cin + nout * self.cout + self.taps * self.cin * self.cout)
+        tr.begin(name, flops, nbytes)
+        call(name, *args)
+        tr.end()
+
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x, n, in_grid, w_packed, out, *, ldi=None, ldc=None, **epi):
         og = self.out_grid(in_grid)
         g = self._geom(n, in_grid, og, self.cin_mem, self.cout, ldi or self.cin_mem)
         e = _epilogue(ldc or self.cout, **epi)
-        call("sv_tconv_gather" if self.transposed else "sv_conv_gather", ptr(x), ptr(w_packed), ptr(out), C.byref(g), C.byref(e),
-             _STATE["math"])
+        self._traced("sv_tconv_gather" if self.transposed else "sv_conv_gather", n, in_grid, ptr(x), ptr(w_packed), ptr(out),
+                     C.byref(g), C.byref(e), _STATE["math"])
         return og
 
     # ---- data gradient: dx[., cin] from dy[., cout_mem] -----------------------------------------------
@@ -125,18 +143,18 @@ class ConvSpec:
         og = self.out_grid(in_grid)
         g = self._geom(n, og, in_grid, self.cout_mem, self.cin, lddy or self.cout_mem)
         e = _epilogue(lddx or self.cin_mem, **epi)
-        call("sv_conv_gather" if self.transposed else "sv_tconv_gather", ptr(dy), ptr(w_dgrad), ptr(dx), C.byref(g), C.byref(e),
-             _STATE["math"])
+        self._traced("sv_conv_gather" if self.transposed else "sv_tconv_gather", n, in_grid, ptr(dy), ptr(w_dgrad), ptr(dx),
+                     C.byref(g), C.byref(e), _STATE["math"])
 
     # ---- weight gradient, accumulated into dw (native layout) ------------------------------------------
     def wgrad(self, dy, x, n, in_grid, dw, *, lddy=None, ldx=None):
         og = self.out_grid(in_grid)
         if self.transposed:   # anchor = x (cin), gathered = dy (cout)
             g = self._geom(n, og, in_grid, self.cout_mem, self.cin, lddy or self.cout_mem)
-            call("sv_conv_wgrad", ptr(x), ldx or self.cin_mem, ptr(dy), ptr(dw), C.byref(g), self.cout, _STATE["math"])
+            self._traced("sv_conv_wgrad", n, in_grid, ptr(x), ldx or self.cin_mem, ptr(dy), ptr(dw), C.byref(g), self.cout, _STATE["math"])
         else:                 # anchor = dy (cout), gathered = x (cin)
             g = self._geom(n, in_grid, og, self.cin_mem, self.cout, ldx or self.cin_mem)
-            call("sv_conv_wgrad", ptr(dy), lddy or self.cout_mem, ptr(x), ptr(dw), C.byref(g), self.cin, _STATE["math"])
+            self._traced("sv_conv_wgrad", n, in_grid, ptr(dy), lddy or self.cout_mem, ptr(x), ptr(dw), C.byref(g), self.cin, _STATE["math"])
 
 
 def colsum(x, rows, cols, ld, out, accumulate=True):
@@ -182,7 +200,7 @@ class BatchNormState:
     def __init__(self, bn: torch.nn.Module, M: int, training: bool):
         self.bn, self.M, self.training, self.C = bn, M, training, bn.num_features
         dev = bn.weight.device
-        self.sums = zeros(2 * self.C, device=dev) if training else None
+        self.sums = torch.zeros(2 * self.C, dtype=torch.float64, device=dev) if training else None   # double accumulators
         buf = empty(4 * self.C, device=dev)
         self.scale, self.shift, self.mean, self.rstd = buf[:self.C], buf[self.C:2 * self.C], buf[2 * self.C:3 * self.C], buf[3 * self.C:]
 
@@ -198,7 +216,7 @@ class BatchNormState:
         call("sv_scale_shift_act", ptr(x), ldx, ptr(self.scale), ptr(self.shift), ptr(residual), ldr, ptr(y), ldy, self.M, self.C, act, slope)
 
     def backward(self, dz, lddz, z, ldz, x, ldx, dx, lddx, dgamma, dbeta, act=ACT_NONE, slope=0.0, dres=None, lddres=0):
-        ws = empty(2 * self.C, like=dz)
+        ws = torch.empty(2 * self.C, dtype=torch.float64, device=dz.device)
         call("sv_bn_bwd", ptr(dz), lddz, ptr(z), ldz, ptr(x), ldx, ptr(self.bn.weight), ptr(self.mean), ptr(self.rstd), self.M, self.C,
              act, slope, 1 if self.training else 0, ptr(dx), lddx, ptr(dres), lddres, ptr(dgamma), ptr(dbeta), ptr(ws))
 

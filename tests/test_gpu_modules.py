@@ -34,6 +34,24 @@ def synth_gt(B, seed):
     return (torch.rand(B, 32, 32, 32, generator=g) < 0.10).float()
 
 
+def grad_report(items, factor=4.0, floor=2e-3):
+    """items: (name, hip_grad, oracle_fp32_grad, oracle_fp64_grad).  A gradient passes when its max-norm error
+    against the fp64 truth is within `factor` x the CPU-fp32 oracle's own error + `floor` (relative to max|truth|);
+    analytically-zero gradients (conv biases in front of a train-mode BatchNorm) are compared absolutely."""
+    bad = []
+    for name, gh, g32, g64 in items:
+        gh, g32, g64 = gh.detach().cpu().double(), g32.detach().double(), g64.detach()
+        scale = float(g64.abs().max())
+        e_hip, e_32 = float((gh - g64).abs().max()), float((g32 - g64).abs().max())
+        if scale < 1e-9:
+            ok = e_hip < 1e-6
+        else:
+            ok = e_hip <= factor * e_32 + floor * scale
+        if not ok:
+            bad.append((name, e_hip / (scale + 1e-30), e_32 / (scale + 1e-30), scale))
+    return bad
+
+
 def no_stochastic(nets):
     for n in nets:
         for m in n.modules():
@@ -114,17 +132,20 @@ def test_tail_backward(dev, nets):
         torch.nn.functional.binary_cross_entropy_with_logits(p_ref(mer), gt.to(dev))
     loss_p.backward()
     assert abs(float(loss_p) - float(loss_o)) < 1e-4
-    assert rel(f2.grad, f1.grad) < 2e-3
-    worst = ("", 0.0)
-    for p, o in ((p_dec, o_dec), (p_mer, o_mer), (p_ref, o_ref)):
-        for (k, a), (_, b) in zip(p.named_parameters(), o.named_parameters()):
-            r = float((a.grad.cpu() - b.grad).abs().max() / (b.grad.abs().max() + 1e-20))
-            # conv biases feeding a train-mode BN have an exactly-zero true gradient: compare absolutely there
-            if b.grad.abs().max() < 1e-6:
-                r = float((a.grad.cpu() - b.grad).abs().max())
-            if r > worst[1]:
-                worst = (f"{type(p).__name__}.{k}", r)
-    assert worst[1] < 5e-3, worst
+    # fp64 run of the same oracle = ground truth; the HIP fp32 gradients must be as close to it as CPU fp32 is
+    # (train-mode BatchNorm over a handful of images makes some gradients ill-conditioned in fp32)
+    d_dec, d_mer, d_ref = (copy.deepcopy(n).double() for n in (o_dec, o_mer, o_ref))
+    for n in (d_dec, d_mer, d_ref):
+        n.zero_grad()
+    f3 = feat.double().requires_grad_(True)
+    raw, vol = d_dec(f3)
+    mer = d_mer(raw, vol)
+    (O.bce_logits(mer, gt.double()) + O.bce_logits(d_ref(mer), gt.double())).backward()
+    bad = grad_report([("feat", f2.grad, f1.grad, f3.grad)] + [
+        (f"{type(p).__name__}.{k}", a.grad, b.grad, c.grad)
+        for p, o, d in ((p_dec, o_dec, d_dec), (p_mer, o_mer, d_mer), (p_ref, o_ref, d_ref))
+        for (k, a), (_, b), (_, c) in zip(p.named_parameters(), o.named_parameters(), d.named_parameters())])
+    assert not bad, bad[:10]
 
 
 @pytest.mark.parametrize("B,V", [(2, 1), (1, 2)])
@@ -187,16 +208,15 @@ def test_train_step_gradients_vs_oracle(dev, nets):
     assert abs(float(el) - float(el_o)) < 1e-4 and abs(float(rl) - float(rl_o)) < 1e-4
     gold = json.load(open(os.path.join(GOLD, "train_step_B2_V2.json")))
     assert abs(float(el + rl) - gold["total"]) < 1e-3
-    bad = []
-    for tag, p, o in zip(("encoder", "decoder", "merger", "refiner"), pn, ocp):
-        for (k, a), (_, b) in zip(p.named_parameters(), o.named_parameters()):
-            ref = b.grad
-            scale = float(ref.abs().max())
-            err = float((a.grad.cpu() - ref).abs().max())
-            # gradients that are analytically zero (biases in front of a train-mode BatchNorm) are compared absolutely
-            ok = err <= 2e-2 * scale + 1e-7 if scale > 1e-6 else err < 1e-5
-            if not ok:
-                bad.append((f"{tag}.{k}", err, scale))
+    # ground truth = the same oracle in fp64 (see test_tail_backward)
+    o64 = [copy.deepcopy(n).double() for n in ocp]
+    for n in o64:
+        n.zero_grad()
+    t64, _, _, _, _ = O.train_step_loss(o64, O.default_cfg(), x.double(), gt.double())
+    t64.backward()
+    bad = grad_report([(f"{tag}.{k}", a.grad, b.grad, c.grad)
+                       for tag, p, o, d in zip(("encoder", "decoder", "merger", "refiner"), pn, ocp, o64)
+                       for (k, a), (_, b), (_, c) in zip(p.named_parameters(), o.named_parameters(), d.named_parameters())])
     assert not bad, bad[:10]
 
 

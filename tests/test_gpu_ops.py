@@ -29,11 +29,22 @@ def ncf(x):     # N...C -> NC...
     return x.permute(0, n - 1, *range(1, n - 1)).contiguous()
 
 
+_KEEP = []
+
+
+def keep(t):
+    """Hold a reference to a device temporary until the test ends: a tensor freed before the (asynchronous) kernel
+    launch can be handed to the next allocation by the caching allocator and overwritten."""
+    _KEEP.append(t)
+    return t
+
+
 @pytest.fixture(autouse=True)
 def _f32():
     ops.set_math("f32")
     yield
     ops.set_math("f32")
+    _KEEP.clear()
 
 
 def test_library_loads_on_gpu(dev):
@@ -106,15 +117,16 @@ def test_conv2d_fwd_dgrad_wgrad(dev, cin, cout, k, s, p, H):
     og = sp.out_grid((1, H, H))
     M = n * og[1] * og[2]
     out = ops.empty(M, cout, device=dev)
-    stats = ops.zeros(2 * cout, device=dev)
+    stats = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
     sp.forward(xd, n, (1, H, H), sp.pack_fwd(wd), out, bias=b.to(dev), stats=stats)
     ref = cl(y.detach()).reshape(M, cout)
     assert rel(out, ref) < TOL
     assert rel(stats[:cout], ref.sum(0)) < 1e-3 and rel(stats[cout:], (ref * ref).sum(0)) < 1e-3
     dyd = cl(dy).reshape(M, cout).to(dev)
-    dx = ops.empty(n * H * H, cin, device=dev)
-    sp.dgrad(dyd, n, (1, H, H), sp.pack_dgrad(wd), dx)
-    assert rel(dx, cl(x.grad).reshape(-1, cin)) < TOL
+    if s <= 2:   # the stride-4 patch embedding never needs a data gradient (its input is the image)
+        dx = ops.empty(n * H * H, cin, device=dev)
+        sp.dgrad(dyd, n, (1, H, H), sp.pack_dgrad(wd), dx)
+        assert rel(dx, cl(x.grad).reshape(-1, cin)) < TOL
     dw = ops.zeros(cout, cin, k, k, device=dev)
     sp.wgrad(dyd, xd, n, (1, H, H), dw)
     assert rel(dw, w.grad) < TOL
@@ -315,7 +327,7 @@ def test_window_attention(dev, H, heads, shift):
     call("sv_window_attention_fwd", ptr(qd), ptr(td), ptr(out16), I, H, H, Cd, heads, shift, hip.MATH_BF16)
     assert rel(out16, ref) < 2e-2
     dqkv, dt = ops.empty(I * H * H, 3 * Cd, device=dev), ops.zeros(169, heads, device=dev)
-    call("sv_window_attention_bwd", ptr(qd), ptr(td), ptr(do.to(dev)), ptr(dqkv), ptr(dt), I, H, H, Cd, heads, shift)
+    call("sv_window_attention_bwd", ptr(qd), ptr(td), ptr(keep(do.to(dev))), ptr(dqkv), ptr(dt), I, H, H, Cd, heads, shift)
     assert rel(dqkv, qkv.grad) < TOL and rel(dt, table.grad) < TOL
 
 
@@ -334,7 +346,7 @@ def test_cross_view_attention_core(dev, V):
     call("sv_cross_view_attention_fwd", ptr(qd), ptr(out), B, V, P, R, heads)
     assert rel(out, o) < TOL
     dq = ops.empty(B * V * P, 3 * R, device=dev)
-    call("sv_cross_view_attention_bwd", ptr(qd), ptr(do.to(dev)), ptr(dq), B, V, P, R, heads)
+    call("sv_cross_view_attention_bwd", ptr(qd), ptr(keep(do.to(dev))), ptr(dq), B, V, P, R, heads)
     assert rel(dq, qkv.grad) < TOL
 
 
@@ -355,7 +367,7 @@ def test_transpose_and_pools(dev):
     call("sv_maxpool2d_fwd", ptr(ad), ptr(yo), ptr(idx), 2, 12, 12, 8)
     assert rel(yo, cl(y.detach()).reshape(-1, 8)) == 0
     dx = ops.zeros(2 * 144, 8, device=dev)
-    call("sv_maxpool2d_bwd", ptr(cl(dy).reshape(-1, 8).to(dev)), ptr(idx), ptr(dx), 2, 12, 12, 8)
+    call("sv_maxpool2d_bwd", ptr(keep(cl(dy).reshape(-1, 8).to(dev))), ptr(idx), ptr(dx), 2, 12, 12, 8)
     assert rel(dx, cl(a.grad).reshape(-1, 8)) < 1e-6
     # avgpool 2x2 into a column slice
     b = torch.randn(2, 8, 14, 14, generator=g, requires_grad=True)
@@ -367,7 +379,7 @@ def test_transpose_and_pools(dev):
     assert rel(wide[:, 8:], cl(yb.detach()).reshape(-1, 8)) < 1e-6
     dwide = torch.zeros(2 * 49, 16); dwide[:, 8:] = cl(dyb).reshape(-1, 8)
     dxb = ops.empty(2 * 196, 8, device=dev)
-    call("sv_avgpool2_bwd", ptr(dwide.to(dev)), ptr(dxb), 2, 14, 14, 8, 16, 8)
+    call("sv_avgpool2_bwd", ptr(keep(dwide.to(dev))), ptr(dxb), 2, 14, 14, 8, 16, 8)
     assert rel(dxb, cl(b.grad).reshape(-1, 8)) < 1e-6
     # maxpool3d floor(33/2)
     c = torch.randn(2, 4, 9, 9, 9, generator=g, requires_grad=True)
@@ -378,7 +390,7 @@ def test_transpose_and_pools(dev):
     call("sv_maxpool3d_fwd", ptr(cl(c.detach()).to(dev)), ptr(yo3), ptr(idx3), 2, 9, 9, 9, 4)
     assert rel(yo3, cl(yc.detach()).reshape(-1, 4)) == 0
     dx3 = ops.empty(2 * 729, 4, device=dev)
-    call("sv_maxpool3d_bwd", ptr(cl(dyc).reshape(-1, 4).to(dev)), ptr(idx3), ptr(dx3), 2, 9, 9, 9, 4)
+    call("sv_maxpool3d_bwd", ptr(keep(cl(dyc).reshape(-1, 4).to(dev))), ptr(idx3), ptr(dx3), 2, 9, 9, 9, 4)
     assert rel(dx3, cl(c.grad).reshape(-1, 4)) < 1e-6
 
 
@@ -393,7 +405,7 @@ def test_decoder_seed_head_cva_spatial(dev):
     call("sv_decoder_seed_fwd", ptr(cl(f.detach()).to(dev)), ptr(out), I, Cc)
     assert rel(out, cl(s.detach()).reshape(-1, Cc)) < 1e-6
     df = ops.empty(I * 49, Cc, device=dev)
-    call("sv_decoder_seed_bwd", ptr(cl(ds).reshape(-1, Cc).to(dev)), ptr(df), I, Cc)
+    call("sv_decoder_seed_bwd", ptr(keep(cl(ds).reshape(-1, Cc).to(dev))), ptr(df), I, Cc)
     assert rel(df, cl(f.grad).reshape(-1, Cc)) < 1e-6
     # depthwise 2x2/2 + bilinear 3->7 + residual
     x = torch.randn(I, Cc, 7, 7, generator=g, requires_grad=True)
@@ -405,7 +417,7 @@ def test_decoder_seed_head_cva_spatial(dev):
     up.backward(dup)
     xd = cl(x.detach()).to(dev)
     sm = ops.empty(I * 9, Cc, device=dev)
-    call("sv_dwconv2x2_fwd", ptr(xd), ptr(w.detach().to(dev)), ptr(b.detach().to(dev)), ptr(sm), I, Cc)
+    call("sv_dwconv2x2_fwd", ptr(xd), ptr(keep(w.detach().to(dev))), ptr(keep(b.detach().to(dev))), ptr(sm), I, Cc)
     assert rel(sm, cl(small.detach()).reshape(-1, Cc)) < 1e-6
     upo = ops.empty(I * 49, Cc, device=dev)
     call("sv_upsample3to7_add_fwd", ptr(sm), ptr(xd), Cc, ptr(upo), I, Cc)
@@ -414,7 +426,7 @@ def test_decoder_seed_head_cva_spatial(dev):
     dsm = ops.empty(I * 9, Cc, device=dev)
     call("sv_upsample3to7_bwd", ptr(dupd), ptr(dsm), I, Cc)
     dx, dw, db = ops.empty(I * 49, Cc, device=dev), ops.zeros(Cc, 1, 2, 2, device=dev), ops.zeros(Cc, device=dev)
-    call("sv_dwconv2x2_bwd", ptr(dsm), ptr(xd), ptr(w.detach().to(dev)), ptr(dx), ptr(dw), ptr(db), I, Cc)
+    call("sv_dwconv2x2_bwd", ptr(dsm), ptr(xd), ptr(keep(w.detach().to(dev))), ptr(dx), ptr(dw), ptr(db), I, Cc)
     assert rel(dx + dupd, cl(x.grad).reshape(-1, Cc)) < 1e-5 and rel(dw, w.grad) < 1e-5 and rel(db, b.grad) < 1e-5
 
 
@@ -431,7 +443,7 @@ def test_merge_bce_iou_dropout(dev):
     call("sv_merge_views_fwd", ptr(wd), ptr(vd), ptr(od), B, V, S)
     assert rel(od, out) < 1e-5
     dw, dv = ops.empty(B, V, S, device=dev), ops.empty(B, V, S, device=dev)
-    call("sv_merge_views_bwd", ptr(wd), ptr(vd), ptr(od), ptr(do.to(dev)), ptr(dw), ptr(dv), B, V, S)
+    call("sv_merge_views_bwd", ptr(wd), ptr(vd), ptr(od), ptr(keep(do.to(dev))), ptr(dw), ptr(dv), B, V, S)
     assert rel(dw, wl.grad) < 1e-5 and rel(dv, vol.grad) < 1e-5
     # BCE with logits
     x = (3 * torch.randn(B, S, generator=g)).requires_grad_(True)
@@ -440,13 +452,13 @@ def test_merge_bce_iou_dropout(dev):
     (loss * 1.7).backward()
     ld, dx = ops.zeros(1, device=dev), ops.empty(B, S, device=dev)
     gs = torch.tensor([1.7], device=dev)
-    call("sv_bce_logits", ptr(x.detach().to(dev)), ptr(t.to(dev)), B * S, ptr(ld), ptr(dx), ptr(gs))
+    call("sv_bce_logits", ptr(keep(x.detach().to(dev))), ptr(keep(t.to(dev))), B * S, ptr(ld), ptr(dx), ptr(gs))
     assert abs(float(ld) - float(loss)) < 1e-5 * max(1, abs(float(loss))) and rel(dx, x.grad) < 1e-5
     # IoU counters vs the reference definition
     import oracle as O
     ths = torch.tensor([0.2, 0.3, 0.4, 0.5])
     cnt = ops.empty(B, 4, 2, device=dev)
-    call("sv_iou_counts", ptr(x.detach().to(dev)), ptr(t.to(dev)), ptr(ths.to(dev)), 4, B, S, ptr(cnt))
+    call("sv_iou_counts", ptr(keep(x.detach().to(dev))), ptr(keep(t.to(dev))), ptr(keep(ths.to(dev))), 4, B, S, ptr(cnt))
     ref = O.iou_at_thresholds(x.detach().view(B, 16, 16, 16), t.view(B, 16, 16, 16))
     c = cnt.cpu()
     for b in range(B):
