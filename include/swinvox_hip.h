@@ -80,9 +80,12 @@ int sv_tconv_gather(const float* in, const float* w_packed, float* out, const sv
                     int math, void* stream);
 /* weight gradient: dw[ca, cg, tap] += sum_r anchor[r, ca] * gathered[r*s - p + tap, cg]   (fp32 atomics; dw pre-zeroed
  * or holding a running sum).  g->Do.. = anchor grid, g->Di.. = gathered grid, g->Co = anchor channels (row stride lda),
- * g->Ci = gathered channels (stride g->ldi); only cg < cg_valid is written; dw index = (ca*cg_valid + cg)*taps + tap.     */
+ * g->Ci = gathered channels (stride g->ldi); only cg < cg_valid is written; dw index = (ca*cg_valid + cg)*taps + tap.
+ * When the kernel has more than one tap the partial sums are gathered in `workspace`
+ * (sv_conv_wgrad_workspace_floats(g) floats, caller-owned, contents destroyed) and folded into dw by a second kernel. */
+size_t sv_conv_wgrad_workspace_floats(const sv_geom* g);
 int sv_conv_wgrad(const float* anchor, int lda, const float* gathered, float* dw, const sv_geom* g, int cg_valid,
-                  int math, void* stream);
+                  float* workspace, int math, void* stream);
 /* dst[a][t][b] (b padded with zeros to bpad) from src[a][b][t]  (swap=0), or dst[b][t][a..apad] (swap=1) */
 int sv_pack_weight(const float* src, float* dst, int A, int B, int T, int swap, int pad_to, void* stream);
 /* per-column sum over rows: out[c] (+)= sum_r x[r*ld + c]  (bias gradients) */

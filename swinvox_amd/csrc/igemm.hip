@@ -1,24 +1,26 @@
 // Implicit-GEMM contraction engine for gfx950 (MFMA 16x16x4 f32 / 16x16x32 bf16, fp32 accumulate).
 //
 // One kernel family serves every Linear / Conv2d / Conv3d / ConvTranspose3d of the SwinVox path:
-//   igemm_kernel<BF16, TCONV>  out[row, co] = epilogue( sum_k A[row, k] * W[co, k] )
+//   igemm_kernel<BF16, TCONV, tile>  out[row, co] = epilogue( sum_k A[row, k] * W[co, k] )
 //       A is never materialised: k = (tap, ci) is decoded to a gathered input position on the fly
 //       (channels-last activations, so the ci run of one tap is contiguous -> 16-byte loads).  The tap
 //       coordinates of a thread's k-chunk advance incrementally from K-step to K-step (no integer division
 //       in the main loop).  TCONV = stride-s transposed gather, decomposed into s^3 output parity classes
 //       (blockIdx.z) so that only taps that really contribute are visited.
-//   wgrad_kernel<BF16>         dw[ca, cg, tap] += sum_r anchor[r, ca] * gathered[pos(r, tap), cg]
-//       reduction over positions, split across blockIdx.z, fp32 atomics into the native weight layout.
-// Tiles: 128x64 outputs per 256-thread workgroup (4 waves as 2x2, each 64x32 = 4x2 MFMA tiles); K-step 32 (fp32)
-// or 64 (bf16); global->register prefetch of step k+1 under the MFMAs of step k (register-staged: the gather
-// needs per-element predication and an fp32->bf16 conversion, which LDS-DMA cannot express).
+//   wgrad_kernel<BF16, tile>         dw[ca, cg, tap] += sum_r anchor[r, ca] * gathered[pos(r, tap), cg]
+//       reduction over positions split across blockIdx.z.  Both operands are stored in LDS as they lie in HBM
+//       ([position][channel], 8/16-byte stores); the MFMA fragments, which need 8 consecutive POSITIONS per lane,
+//       are produced by the transposing LDS read ds_read_b64_tr_b16 (bf16) or plain strided reads (fp32).
+// Tile shapes (256 threads = 4 waves): 128x64 default, 128x128 for wide outputs, 128x16 for the <=16-channel
+// 3-D tail (merger / decoder head / refiner head), so that narrow layers do not pay for padded MFMA columns.
+// K-step 32 (fp32) or 64 (bf16); global->register prefetch of step k+1 under the MFMAs of step k
+// (register-staged: the gather needs per-element predication and an fp32->bf16 conversion).
 #include "common.h"
 
 namespace sv {
 
-constexpr int BM = 128, BN = 64;
-constexpr int PAD_F32 = 4;   // floats  -> row stride 36 floats (144 B, 16-B aligned)
-constexpr int PAD_BF16 = 8;  // bf16    -> row stride 72 bf16 (144 B, 16-B aligned)
+constexpr int PAD_F32 = 4;   // floats
+constexpr int PAD_BF16 = 8;  // bf16     (both = 16 bytes: keeps every row 16-byte aligned)
 
 struct Geom {
   int N, Di, Hi, Wi, Do, Ho, Wo, Ci, Co, kd, kh, kw, sd, sh, sw, pd, ph, pw, ldi;
@@ -48,46 +50,103 @@ template <> struct Cfg<true> {
   typedef __bf16 T; static constexpr int BK = 64; static constexpr int PAD = PAD_BF16;
 };
 
+// wave grid WM x WN (WM*WN == 4), each wave MT x NT tiles of 16x16
+template <int WM_, int WN_, int MT_, int NT_> struct Tile {
+  static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_;
+  static constexpr int BM = WM_ * MT_ * 16, BN = WN_ * NT_ * 16;
+};
+typedef Tile<2, 2, 4, 2> TileDefault;   // 128 x 64
+typedef Tile<2, 2, 4, 4> TileWide;      // 128 x 128
+typedef Tile<4, 1, 2, 1> TileNarrow;    // 128 x 16
+
 __device__ __forceinline__ void store4(float* dst, float4 v) { *reinterpret_cast<float4*>(dst) = v; }
 __device__ __forceinline__ void store4(__bf16* dst, float4 v) {
   bf16x4 b;
   b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
   *reinterpret_cast<bf16x4*>(dst) = b;
 }
-__device__ __forceinline__ void store1(float* dst, float v) { *dst = v; }
-__device__ __forceinline__ void store1(__bf16* dst, float v) { *dst = (__bf16)v; }
 
-// acc[4][2] += A(64 rows of this wave) x B(32 cols of this wave) over one K-step slab in LDS
-template <bool BF16>
+// ---- MFMA over one K-step slab, operands stored [row][k] (k contiguous) ---------------------------
+template <bool BF16, int MT, int NT>
 __device__ __forceinline__ void mma_slab(const typename Cfg<BF16>::T* As, const typename Cfg<BF16>::T* Bs,
-                                         int wm, int wn, int lane, f32x4 (&acc)[4][2]) {
+                                         int arow0, int brow0, int lane, f32x4 (&acc)[MT][NT]) {
   constexpr int BK = Cfg<BF16>::BK, LD = BK + Cfg<BF16>::PAD;
   const int lr = lane & 15, lg = lane >> 4;
   if constexpr (BF16) {
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 a[4], b[2];
+      bf16x8 a[MT], b[NT];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(As + (wm * 64 + mt * 16 + lr) * LD + ks * 32 + lg * 8);
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(As + (arow0 + mt * 16 + lr) * LD + ks * 32 + lg * 8);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(Bs + (wn * 32 + nt * 16 + lr) * LD + ks * 32 + lg * 8);
+      for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(Bs + (brow0 + nt * 16 + lr) * LD + ks * 32 + lg * 8);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
     }
   } else {
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      float a[4], b[2];
+      float a[MT], b[NT];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) a[mt] = As[(wm * 64 + mt * 16 + lr) * LD + kk * 4 + lg];
+      for (int mt = 0; mt < MT; ++mt) a[mt] = As[(arow0 + mt * 16 + lr) * LD + kk * 4 + lg];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) b[nt] = Bs[(wn * 32 + nt * 16 + lr) * LD + kk * 4 + lg];
+      for (int nt = 0; nt < NT; ++nt) b[nt] = Bs[(brow0 + nt * 16 + lr) * LD + kk * 4 + lg];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+}
+
+// ---- MFMA over one K-step slab, operands stored [k][col] (as they lie in HBM) -----------------------
+// bf16: ds_read_b64_tr_b16 delivers, per 16-lane group, a 4(k) x 16(col) block column-major: lane i of the group
+// gets column i, rows 0..3; lane 4q+p supplies the address of row q, columns 4p..4p+3.  Two reads give the 8
+// consecutive k of the 16x16x32 fragment (k = 8*(lane>>4) + j).
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+template <bool BF16, int MT, int NT, int LDA, int LDB>
+__device__ __forceinline__ void mma_slab_km(const typename Cfg<BF16>::T* As, const typename Cfg<BF16>::T* Bs,
+                                            int acol0, int bcol0, int lane, f32x4 (&acc)[MT][NT]) {
+  constexpr int BK = Cfg<BF16>::BK;
+  const int lr = lane & 15, lg = lane >> 4;
+  if constexpr (BF16) {
+    const int q = lr >> 2, pp = lr & 3;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 a[MT], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const __bf16* src = As + (ks * 32 + lg * 8 + q) * LDA + acol0 + mt * 16 + pp * 4;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src + 4 * LDA));
+        a[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const __bf16* src = Bs + (ks * 32 + lg * 8 + q) * LDB + bcol0 + nt * 16 + pp * 4;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(src + 4 * LDB));
+        b[nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      float a[MT], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = As[(kk * 4 + lg) * LDA + acol0 + mt * 16 + lr];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = Bs[(kk * 4 + lg) * LDB + bcol0 + nt * 16 + lr];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
     }
   }
 }
@@ -103,19 +162,21 @@ __device__ __forceinline__ void decode_row(int m, int c0, int c1, int c2, int& n
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------------
-template <bool BF16, bool TCONV>
+template <bool BF16, bool TCONV, typename TL>
 __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
   typedef typename Cfg<BF16>::T LT;
   constexpr int BK = Cfg<BF16>::BK, LD = BK + Cfg<BF16>::PAD;
+  constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT;
   constexpr int TPR = BK / 4;          // threads per tile row (one float4 each)
   constexpr int RPP = 256 / TPR;       // rows per pass
-  constexpr int NA = BM / RPP, NB = BN / RPP;
+  constexpr int NA = BM / RPP;
+  constexpr int NB = (BN + RPP - 1) / RPP;
   __shared__ __attribute__((aligned(16))) LT As[BM * LD];
   __shared__ __attribute__((aligned(16))) LT Bs[BN * LD];
 
   const Geom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / TL::WN, wn = wave % TL::WN;
 
   int cnt0, cnt1, cnt2, T0, T1, T2;
   ClassInfo ci;
@@ -185,8 +246,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int n = col0 + rb + RPP * i;
-        if (n < g.Co && kok) rbv[i] = *reinterpret_cast<const float4*>(p.w + (size_t)n * p.Ktot + woff);
+        const int nl = rb + RPP * i, n = col0 + nl;
+        if (nl < BN && n < g.Co && kok) rbv[i] = *reinterpret_cast<const float4*>(p.w + (size_t)n * p.Ktot + woff);
         else rbv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       // advance
@@ -214,13 +275,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int n = col0 + rb + RPP * i;
+        const int nl = rb + RPP * i, n = col0 + nl;
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int kk = kcur + j;
           float val = 0.f;
-          if (n < g.Co && kk < K) {
+          if (nl < BN && n < g.Co && kk < K) {
             int kidx = kk;
             if constexpr (TCONV) {
               const int tap = kk / g.Ci, c = kk - tap * g.Ci;
@@ -241,14 +302,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) store4(As + (rb + RPP * i) * LD + kq, ra[i]);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) store4(Bs + (rb + RPP * i) * LD + kq, rbv[i]);
+    for (int i = 0; i < NB; ++i)
+      if (rb + RPP * i < BN) store4(Bs + (rb + RPP * i) * LD + kq, rbv[i]);
   };
 
-  f32x4 acc[4][2];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = (K + BK - 1) / BK;
   if (nk > 0) {
@@ -257,7 +319,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) load_tile();
-      mma_slab<BF16>(As, Bs, wm, wn, lane, acc);
+      mma_slab<BF16, MT, NT>(As, Bs, wm * MT * 16, wn * NT * 16, lane, acc);
       __syncthreads();
       if (kt + 1 < nk) {
         store_tile();
@@ -269,12 +331,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
   // ---- epilogue: C tile element (row = (lane>>4)*4 + j, col = lane&15) ---------------------------
   const Epi& e = p.e;
   const int lr = lane & 15, lg = lane >> 4;
-  int pos[4][4];   // output position (pixel index) of this lane's 16 rows, -1 = out of range
+  int pos[MT][4];   // output position (pixel index) of this lane's rows, -1 = out of range
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int m = row0 + wm * 64 + mt * 16 + lg * 4 + j;
+      const int m = row0 + (wm * MT + mt) * 16 + lg * 4 + j;
       int ps = -1;
       if (m < Mrows) {
         if constexpr (TCONV) {
@@ -289,13 +351,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
       pos[mt][j] = ps;
     }
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int n = col0 + wn * 32 + nt * 16 + lr;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = col0 + (wn * NT + nt) * 16 + lr;
     const bool nok = n < g.Co;
     const float bias = (nok && e.bias) ? e.bias[n] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int ps = pos[mt][j];
@@ -329,22 +391,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
 // weight-gradient kernel
 // ------------------------------------------------------------------------------------------------
 struct WGradArgs {
-  const float* anchor; int lda; const float* gathered; float* dw;
-  Geom g; int cg_valid; int rows_per_split; int Mrows;
+  const float* anchor; int lda; const float* gathered; float* out;   // out = dw (taps == 1) or the packed workspace
+  Geom g; int cg_valid; int rows_per_split; int Mrows; int direct;
 };
 
-template <bool BF16>
+template <bool BF16, typename TL>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs p) {
   typedef typename Cfg<BF16>::T LT;
-  constexpr int BK = Cfg<BF16>::BK, LD = BK + Cfg<BF16>::PAD;
-  constexpr int NAR = BK / 8;    // A: 32 threads span 128 ca (float4 each) -> 8 rows per pass
-  constexpr int NBR = BK / 16;   // B: 16 threads span 64 k_out            -> 16 rows per pass
-  __shared__ __attribute__((aligned(16))) LT As[BM * LD];  // [ca][r]
-  __shared__ __attribute__((aligned(16))) LT Bs[BN * LD];  // [k_out][r]
+  constexpr int BK = Cfg<BF16>::BK, PAD = Cfg<BF16>::PAD;
+  constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT;
+  constexpr int LDA = BM + PAD, LDB = BN + PAD;
+  constexpr int A4 = BM / 4, A_RPP = 256 / A4, A_PASS = (BK + A_RPP - 1) / A_RPP;   // float4 columns / rows per pass / passes
+  constexpr int B4 = BN / 4, B_RPP = 256 / B4, B_PASS = (BK + B_RPP - 1) / B_RPP;
+  __shared__ __attribute__((aligned(16))) LT As[BK * LDA];  // [r][ca]
+  __shared__ __attribute__((aligned(16))) LT Bs[BK * LDB];  // [r][k_out]
 
   const Geom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / TL::WN, wn = wave % TL::WN;
   const int taps = g.kd * g.kh * g.kw;
   const int Kout = taps * g.Ci;
   const int ca0 = blockIdx.x * BM, ko0 = blockIdx.y * BN;
@@ -353,8 +417,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs p) {
   if (r_end > p.Mrows) r_end = p.Mrows;
   if (r_begin >= r_end) return;
 
-  const int a_c = (tid & 31) * 4, a_r = tid >> 5;
-  const int b_k = ko0 + (tid & 15) * 4, b_r = tid >> 4;
+  const int a_c = (tid % A4) * 4, a_r = tid / A4;
+  const int b_kl = (tid % B4) * 4, b_k = ko0 + b_kl, b_r = tid / B4;
   const bool avec = (p.lda & 3) == 0, bvec = (g.Ci & 3) == 0 && (g.ldi & 3) == 0;
   const bool dense = (g.Do * g.Ho * g.Wo == 1) && taps == 1;   // Linear: gathered row == anchor row
   int b_c = 0, b_td = 0, b_th = 0, b_tw = 0;
@@ -363,18 +427,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs p) {
     b_tw = b_tap % g.kw; const int t2 = b_tap / g.kw; b_th = t2 % g.kh; b_td = t2 / g.kh;
   }
   // running (n,d,h,w) of the rows this thread gathers for B; advanced by BK per step without division
-  int bn_[NBR], bd_[NBR], bh_[NBR], bw_[NBR];
+  int bn_[B_PASS], bd_[B_PASS], bh_[B_PASS], bw_[B_PASS];
 #pragma unroll
-  for (int i = 0; i < NBR; ++i) decode_row(r_begin + b_r + 16 * i, g.Do, g.Ho, g.Wo, bn_[i], bd_[i], bh_[i], bw_[i]);
+  for (int i = 0; i < B_PASS; ++i) decode_row(r_begin + b_r + B_RPP * i, g.Do, g.Ho, g.Wo, bn_[i], bd_[i], bh_[i], bw_[i]);
 
-  float4 ra[NAR], rbv[NBR];
+  float4 ra[A_PASS], rbv[B_PASS];
   int r0 = r_begin;
   auto load_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < NAR; ++i) {
-      const int r = r0 + a_r + 8 * i;
+    for (int i = 0; i < A_PASS; ++i) {
+      const int rl = a_r + A_RPP * i, r = r0 + rl;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (r < r_end) {
+      if (rl < BK && r < r_end) {
         const float* src = p.anchor + (size_t)r * p.lda + ca0 + a_c;
         if (avec && ca0 + a_c + 3 < g.Co) {
           const float4 q = *reinterpret_cast<const float4*>(src);
@@ -387,10 +451,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs p) {
       ra[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
 #pragma unroll
-    for (int i = 0; i < NBR; ++i) {
-      const int r = r0 + b_r + 16 * i;
+    for (int i = 0; i < B_PASS; ++i) {
+      const int rl = b_r + B_RPP * i, r = r0 + rl;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (r < r_end) {
+      if (rl < BK && r < r_end) {
         if (dense) {
           if (bvec) {
             if (b_k < Kout) {
@@ -431,7 +495,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs p) {
     r0 += BK;
     if (!dense) {
 #pragma unroll
-      for (int i = 0; i < NBR; ++i) {
+      for (int i = 0; i < B_PASS; ++i) {
         bw_[i] += BK;
         while (bw_[i] >= g.Wo) {
           bw_[i] -= g.Wo;
@@ -440,27 +504,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs p) {
       }
     }
   };
-  auto store_tile = [&]() {  // transposing stores: reduction index r becomes the contiguous LDS dimension
+  auto store_tile = [&]() {  // natural layout: [position][channel], vector stores
 #pragma unroll
-    for (int i = 0; i < NAR; ++i) {
-      const int r = a_r + 8 * i;
-      store1(As + (a_c + 0) * LD + r, ra[i].x); store1(As + (a_c + 1) * LD + r, ra[i].y);
-      store1(As + (a_c + 2) * LD + r, ra[i].z); store1(As + (a_c + 3) * LD + r, ra[i].w);
+    for (int i = 0; i < A_PASS; ++i) {
+      const int rl = a_r + A_RPP * i;
+      if (rl < BK) store4(As + rl * LDA + a_c, ra[i]);
     }
 #pragma unroll
-    for (int i = 0; i < NBR; ++i) {
-      const int r = b_r + 16 * i;
-      const int kl = (tid & 15) * 4;
-      store1(Bs + (kl + 0) * LD + r, rbv[i].x); store1(Bs + (kl + 1) * LD + r, rbv[i].y);
-      store1(Bs + (kl + 2) * LD + r, rbv[i].z); store1(Bs + (kl + 3) * LD + r, rbv[i].w);
+    for (int i = 0; i < B_PASS; ++i) {
+      const int rl = b_r + B_RPP * i;
+      if (rl < BK) store4(Bs + rl * LDB + b_kl, rbv[i]);
     }
   };
 
-  f32x4 acc[4][2];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   load_tile();
   store_tile();
@@ -468,7 +529,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs p) {
   for (int rr = r_begin; rr < r_end; rr += BK) {
     const bool more = rr + BK < r_end;
     if (more) load_tile();
-    mma_slab<BF16>(As, Bs, wm, wn, lane, acc);
+    mma_slab_km<BF16, MT, NT, LDA, LDB>(As, Bs, wm * MT * 16, wn * NT * 16, lane, acc);
     __syncthreads();
     if (more) {
       store_tile();
@@ -478,18 +539,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs p) {
 
   const int lr = lane & 15, lg = lane >> 4;
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int ko = ko0 + wn * 32 + nt * 16 + lr;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ko = ko0 + (wn * NT + nt) * 16 + lr;
     if (ko >= Kout) continue;
     const int tap = ko / g.Ci, cg = ko - tap * g.Ci;
     if (cg >= p.cg_valid) continue;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int ca = ca0 + wm * 64 + mt * 16 + lg * 4 + j;
-        if (ca < g.Co) atomicAdd(p.dw + ((size_t)ca * p.cg_valid + cg) * taps + tap, acc[mt][nt][j]);
+        const int ca = ca0 + (wm * MT + mt) * 16 + lg * 4 + j;
+        if (ca < g.Co) {
+          // direct: native layout (taps == 1 -> contiguous along cg); else packed workspace [ca][tap][cg] (contiguous along ko)
+          const size_t o = p.direct ? ((size_t)ca * p.cg_valid + cg) * taps + tap : (size_t)ca * Kout + ko;
+          atomicAdd(p.out + o, acc[mt][nt][j]);
+        }
       }
+  }
+}
+
+// dw[(ca*cgv + cg)*taps + tap] += ws[ca*Kout + tap*Ci + cg]
+__global__ void wgrad_unpack_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Co, int Ci, int cgv, int taps) {
+  const long long total = (long long)Co * cgv * taps;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps); long long t = i / taps;
+    const int cg = (int)(t % cgv); const int ca = (int)(t / cgv);
+    dw[i] += ws[((size_t)ca * taps + tap) * Ci + cg];
   }
 }
 
@@ -550,6 +625,28 @@ static int check_common(const sv_geom* g, const sv_epilogue* e, const void* in, 
   return SV_OK;
 }
 
+template <bool TCONV>
+static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, hipStream_t s) {
+  const int Co = a.g.Co;
+  const bool bf = math == SV_MATH_BF16;
+  if (Co <= 16) {
+    dim3 grid(cdiv(M, TileNarrow::BM), cdiv(Co, TileNarrow::BN), ncls);
+    if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileNarrow>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileNarrow>), grid, dim3(256), 0, s, a);
+  } else if (Co % 128 == 0 && (long long)cdiv(M, 128) * (Co / 128) * ncls >= 512) {
+    dim3 grid(cdiv(M, TileWide::BM), cdiv(Co, TileWide::BN), ncls);
+    if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileWide>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileWide>), grid, dim3(256), 0, s, a);
+  } else {
+    dim3 grid(cdiv(M, TileDefault::BM), cdiv(Co, TileDefault::BN), ncls);
+    if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileDefault>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileDefault>), grid, dim3(256), 0, s, a);
+  }
+}
+
+typedef Tile<2, 2, 4, 2> WTileDefault;   // 128 anchor channels x 64 (tap, gathered channel)
+typedef Tile<1, 4, 1, 2> WTileNarrow;    // 16 x 128 for <=16 anchor channels
+
 }  // namespace sv
 
 using namespace sv;
@@ -561,10 +658,7 @@ extern "C" int sv_conv_gather(const float* in, const float* w, float* out, const
   a.x = in; a.w = w; a.y = out; a.g = to_geom(g); a.e = to_epi(e);
   a.Ktot = g->kd * g->kh * g->kw * g->Ci;
   const long long M = (long long)g->N * g->Do * g->Ho * g->Wo;
-  dim3 grid(cdiv(M, BM), cdiv(g->Co, BN), 1);
-  hipStream_t s = (hipStream_t)stream;
-  if (math == SV_MATH_BF16) hipLaunchKernelGGL((igemm_kernel<true, false>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((igemm_kernel<false, false>), grid, dim3(256), 0, s, a);
+  launch_igemm<false>(a, M, 1, math, (hipStream_t)stream);
   return check_launch("sv_conv_gather");
 }
 
@@ -597,27 +691,37 @@ extern "C" int sv_tconv_gather(const float* in, const float* w, float* out, cons
         a.cls[ncls++] = c;
       }
   if (maxM == 0) return SV_OK;
-  dim3 grid(cdiv(maxM, BM), cdiv(g->Co, BN), ncls);
-  hipStream_t s = (hipStream_t)stream;
-  if (math == SV_MATH_BF16) hipLaunchKernelGGL((igemm_kernel<true, true>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((igemm_kernel<false, true>), grid, dim3(256), 0, s, a);
+  launch_igemm<true>(a, maxM, ncls, math, (hipStream_t)stream);
   return check_launch("sv_tconv_gather");
 }
 
+extern "C" size_t sv_conv_wgrad_workspace_floats(const sv_geom* g) {
+  const int taps = g->kd * g->kh * g->kw;
+  return taps == 1 ? 0 : (size_t)g->Co * taps * g->Ci;
+}
+
 extern "C" int sv_conv_wgrad(const float* anchor, int lda, const float* gathered, float* dw, const sv_geom* g, int cg_valid,
-                             int math, void* stream) {
+                             float* workspace, int math, void* stream) {
   SV_REQUIRE(anchor && gathered && dw && g, "wgrad: null argument");
   SV_REQUIRE(lda >= g->Co && g->ldi >= g->Ci && cg_valid > 0 && cg_valid <= g->Ci, "wgrad: bad strides (lda=%d Co=%d ldi=%d Ci=%d cg_valid=%d)",
              lda, g->Co, g->ldi, g->Ci, cg_valid);
   SV_REQUIRE(((uintptr_t)anchor & 15) == 0 && ((uintptr_t)gathered & 15) == 0, "wgrad: operands must be 16-byte aligned");
   const long long Mll = (long long)g->N * g->Do * g->Ho * g->Wo;
   SV_REQUIRE(Mll > 0 && Mll < (1ll << 31), "wgrad: row count out of range");
+  const int taps = g->kd * g->kh * g->kw;
+  const int Kout = taps * g->Ci;
+  SV_REQUIRE(taps == 1 || workspace, "wgrad: a workspace of sv_conv_wgrad_workspace_floats() floats is required when taps > 1");
+  hipStream_t s = (hipStream_t)stream;
   WGradArgs a{};
-  a.anchor = anchor; a.lda = lda; a.gathered = gathered; a.dw = dw; a.g = to_geom(g); a.cg_valid = cg_valid;
+  a.anchor = anchor; a.lda = lda; a.gathered = gathered; a.g = to_geom(g); a.cg_valid = cg_valid;
   a.Mrows = (int)Mll;
+  a.direct = taps == 1;
+  a.out = a.direct ? dw : workspace;
+  if (!a.direct) (void)hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)g->Co * Kout, s);
+  const bool narrow = g->Co <= 16;
+  const int BMw = narrow ? WTileNarrow::BM : WTileDefault::BM, BNw = narrow ? WTileNarrow::BN : WTileDefault::BN;
   const int BKs = math == SV_MATH_BF16 ? 64 : 32;
-  const int Kout = g->kd * g->kh * g->kw * g->Ci;
-  const int tiles = cdiv(g->Co, BM) * cdiv(Kout, BN);
+  const int tiles = cdiv(g->Co, BMw) * cdiv(Kout, BNw);
   // enough splits to fill ~4 workgroups per CU, but at least 4 K-steps of work per split
   long long splits = (1024 + tiles - 1) / tiles;
   const long long max_splits = (Mll + 4 * BKs - 1) / (4 * BKs);
@@ -628,10 +732,20 @@ extern "C" int sv_conv_wgrad(const float* anchor, int lda, const float* gathered
   rps = (rps + BKs - 1) / BKs * BKs;
   splits = (Mll + rps - 1) / rps;
   a.rows_per_split = (int)rps;
-  dim3 grid(cdiv(g->Co, BM), cdiv(Kout, BN), (unsigned)splits);
-  hipStream_t s = (hipStream_t)stream;
-  if (math == SV_MATH_BF16) hipLaunchKernelGGL((wgrad_kernel<true>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((wgrad_kernel<false>), grid, dim3(256), 0, s, a);
+  dim3 grid(cdiv(g->Co, BMw), cdiv(Kout, BNw), (unsigned)splits);
+  const bool bf = math == SV_MATH_BF16;
+  if (narrow) {
+    if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileNarrow>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<false, WTileNarrow>), grid, dim3(256), 0, s, a);
+  } else {
+    if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileDefault>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<false, WTileDefault>), grid, dim3(256), 0, s, a);
+  }
+  if (!a.direct) {
+    const long long total = (long long)g->Co * cg_valid * taps;
+    int blocks = cdiv(total, 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(blocks), dim3(256), 0, s, workspace, dw, g->Co, g->Ci, cg_valid, taps);
+  }
   return check_launch("sv_conv_wgrad");
 }
 

@@ -151,10 +151,14 @@ class ConvSpec:
         og = self.out_grid(in_grid)
         if self.transposed:   # anchor = x (cin), gathered = dy (cout)
             g = self._geom(n, og, in_grid, self.cout_mem, self.cin, lddy or self.cout_mem)
-            self._traced("sv_conv_wgrad", n, in_grid, ptr(x), ldx or self.cin_mem, ptr(dy), ptr(dw), C.byref(g), self.cout, _STATE["math"])
+            ws = empty(self.cin * self.taps * self.cout_mem, like=dw) if self.taps > 1 else None
+            self._traced("sv_conv_wgrad", n, in_grid, ptr(x), ldx or self.cin_mem, ptr(dy), ptr(dw), C.byref(g), self.cout, ptr(ws),
+                         _STATE["math"])
         else:                 # anchor = dy (cout), gathered = x (cin)
             g = self._geom(n, in_grid, og, self.cin_mem, self.cout, ldx or self.cin_mem)
-            self._traced("sv_conv_wgrad", n, in_grid, ptr(dy), lddy or self.cout_mem, ptr(x), ptr(dw), C.byref(g), self.cin, _STATE["math"])
+            ws = empty(self.cout * self.taps * self.cin_mem, like=dw) if self.taps > 1 else None
+            self._traced("sv_conv_wgrad", n, in_grid, ptr(dy), lddy or self.cout_mem, ptr(x), ptr(dw), C.byref(g), self.cin, ptr(ws),
+                         _STATE["math"])
 
 
 def colsum(x, rows, cols, ld, out, accumulate=True):
