@@ -32,6 +32,7 @@ extern "C" {
 #define SV_ERR_LAUNCH (-2)
 
 enum { SV_ACT_NONE = 0, SV_ACT_RELU = 1, SV_ACT_GELU = 2, SV_ACT_LRELU = 3 };
+#define SV_BN_SLOTS 16 /* BatchNorm statistic accumulators are [SV_BN_SLOTS][2*C] doubles (contention spreading) */
 enum { SV_MATH_F32 = 0, SV_MATH_BF16 = 1 }; /* MFMA input type of the contraction kernels; I/O and accumulation stay fp32 */
 
 const char* sv_last_error(void);
@@ -62,7 +63,7 @@ typedef struct sv_epilogue {
   const float* row_scale; /* optional per-image scale of val before the residual add (drop-path), index = row / rows_per_scale */
   int rows_per_scale;
   float* pre_act;        /* optional: receives val (after bias, before activation), same layout as out */
-  double* stats;         /* optional [2*Co] DOUBLES: atomically accumulates sum and sum-of-squares of the stored output per channel */
+  double* stats;         /* optional [SV_BN_SLOTS][2*Co] DOUBLES: atomically accumulates sum and sum-of-squares of the stored output per channel */
   int act;               /* SV_ACT_* applied to val (after bias) */
   float slope;           /* LeakyReLU slope */
   const float* act_grad_src; /* optional: val *= act'(act_grad_src[pos]) (backward through an activation), layout of out */
@@ -108,8 +109,8 @@ size_t sv_ln_image_workspace_floats(int I, int L);
 int sv_ln_image_fwd(const float* x, const float* w, const float* b, float* y, float* meanrstd, float* workspace,
                     int I, int L, float eps, float drop_p, uint32_t seed, void* stream);
 int sv_ln_image_bwd(const float* dy, const float* x, const float* w, const float* meanrstd, float* dx, float* dw,
-                    float* db, float* sums_ws, int I, int L, float drop_p, uint32_t seed, void* stream);
-int sv_bn_stats(const float* x, long long M, int C, int ld, double* sums, void* stream);   /* sums: [2*C] doubles */
+                    float* db, double* sums_ws /* [2*I] doubles */, int I, int L, float drop_p, uint32_t seed, void* stream);
+int sv_bn_stats(const float* x, long long M, int C, int ld, double* sums, void* stream);   /* sums: [SV_BN_SLOTS][2*C] doubles (slot 0 is used) */
 int sv_bn_finalize(const double* sums, long long count, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float momentum, float eps, int training, float* scale, float* shift,
                    float* save_mean, float* save_rstd, int C, void* stream);

@@ -83,7 +83,7 @@ __device__ __forceinline__ void bias_mask_softmax(f32x4 (&s)[4][4], const float*
       mx = group16_max(mx);
       float sum = 0.f;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) { const float e = __expf(s[mt][nt][j] - mx); s[mt][nt][j] = e; sum += e; }
+      for (int nt = 0; nt < 4; ++nt) { const float e = expf(s[mt][nt][j] - mx); s[mt][nt][j] = e; sum += e; }
       const float inv = 1.f / group16_sum(sum);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) s[mt][nt][j] *= inv;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void cva_attn_fwd_kernel(const CvaArgs p) {
     float mx = -3.0e38f;
     for (int j = 0; j < V; ++j) mx = fmaxf(mx, a[i * V + j]);
     float sum = 0.f;
-    for (int j = 0; j < V; ++j) { const float e = __expf(a[i * V + j] - mx); a[i * V + j] = e; sum += e; }
+    for (int j = 0; j < V; ++j) { const float e = expf(a[i * V + j] - mx); a[i * V + j] = e; sum += e; }
     const float inv = 1.f / sum;
     for (int j = 0; j < V; ++j) a[i * V + j] *= inv;
   }
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void cva_attn_bwd_kernel(const CvaArgs p) {
     float mx = -3.0e38f;
     for (int j = 0; j < V; ++j) mx = fmaxf(mx, a[i * V + j]);
     float sum = 0.f;
-    for (int j = 0; j < V; ++j) { const float e = __expf(a[i * V + j] - mx); a[i * V + j] = e; sum += e; }
+    for (int j = 0; j < V; ++j) { const float e = expf(a[i * V + j] - mx); a[i * V + j] = e; sum += e; }
     const float inv = 1.f / sum;
     float r = 0.f;
     for (int j = 0; j < V; ++j) { a[i * V + j] *= inv; r += a[i * V + j] * ds[i * V + j]; }

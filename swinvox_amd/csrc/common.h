@@ -53,7 +53,7 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
 

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void merge_views_fwd_kernel(const float* __res
     float mx = -3.4e38f;
     for (int v = 0; v < V; ++v) mx = fmaxf(mx, wp[(size_t)v * S]);
     float den = 0.f, num = 0.f;
-    for (int v = 0; v < V; ++v) { const float e = __expf(wp[(size_t)v * S] - mx); den += e; num += e * vp[(size_t)v * S]; }
+    for (int v = 0; v < V; ++v) { const float e = expf(wp[(size_t)v * S] - mx); den += e; num += e * vp[(size_t)v * S]; }
     out[i] = num / den;
   }
 }
@@ -354,10 +354,10 @@ __global__ __launch_bounds__(256) void merge_views_bwd_kernel(const float* __res
     float mx = -3.4e38f;
     for (int v = 0; v < V; ++v) mx = fmaxf(mx, wl[base + (size_t)v * S]);
     float den = 0.f;
-    for (int v = 0; v < V; ++v) den += __expf(wl[base + (size_t)v * S] - mx);
+    for (int v = 0; v < V; ++v) den += expf(wl[base + (size_t)v * S] - mx);
     const float g = dout[i], o = out[i], inv = 1.f / den;
     for (int v = 0; v < V; ++v) {
-      const float pv = __expf(wl[base + (size_t)v * S] - mx) * inv;
+      const float pv = expf(wl[base + (size_t)v * S] - mx) * inv;
       dvol[base + (size_t)v * S] = g * pv;
       dwl[base + (size_t)v * S] = pv * g * (vol[base + (size_t)v * S] - o);
     }
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ x, c
   float acc = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float xv = x[i], tv = t[i];
-    const float e = __expf(-fabsf(xv));
+    const float e = expf(-fabsf(xv));
     acc += fmaxf(xv, 0.f) - xv * tv + log1pf(e);
     if (dx) {
       const float sig = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void iou_counts_kernel(const float* __restrict
     float inter = 0.f, uni = 0.f;
     for (int s = threadIdx.x; s < S; s += 256) {
       const float xv = logits[(size_t)b * S + s];
-      const float pr = 1.f / (1.f + __expf(-xv));
+      const float pr = 1.f / (1.f + expf(-xv));
       const float v = pr >= th ? 1.f : 0.f, gv = gt[(size_t)b * S + s];
       inter += v * gv; uni += (v + gv >= 1.f) ? 1.f : 0.f;
     }

@@ -171,8 +171,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
   constexpr int RPP = 256 / TPR;       // rows per pass
   constexpr int NA = BM / RPP;
   constexpr int NB = (BN + RPP - 1) / RPP;
-  __shared__ __attribute__((aligned(16))) LT As[BM * LD];
-  __shared__ __attribute__((aligned(16))) LT Bs[BN * LD];
+  constexpr int LDC = BN + 4;          // fp32 staging tile of the epilogue (aliases the operand tiles)
+  constexpr int AB_BYTES = (BM + BN) * LD * (int)sizeof(LT), C_BYTES = BM * LDC * 4;
+  __shared__ __attribute__((aligned(16))) char smem[AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES];
+  __shared__ float red[4 * BN * 2];
+  LT* As = reinterpret_cast<LT*>(smem);
+  LT* Bs = As + BM * LD;
+  float* Cs = reinterpret_cast<float*>(smem);
 
   const Geom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -328,61 +333,97 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
     }
   }
 
-  // ---- epilogue: C tile element (row = (lane>>4)*4 + j, col = lane&15) ---------------------------
+  // ---- epilogue: accumulators -> LDS tile -> cooperative, row-contiguous (16-byte) reads/writes -----------------
   const Epi& e = p.e;
-  const int lr = lane & 15, lg = lane >> 4;
-  int pos[MT][4];   // output position (pixel index) of this lane's rows, -1 = out of range
+  {
+    const int lr = lane & 15, lg = lane >> 4;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          Cs[((wm * MT + mt) * 16 + lg * 4 + j) * LDC + (wn * NT + nt) * 16 + lr] = acc[mt][nt][j];
+  }
+  __syncthreads();
+  constexpr int C4 = BN / 4, CRPP = 256 / C4, CPASS = BM / CRPP;
+  const int c4 = tid % C4, cr = tid / C4;
+  const int n0 = col0 + c4 * 4;
+  const bool vec_out = ((e.ldc | e.col_off | g.Co) & 3) == 0 && (!e.residual || (e.ldr & 3) == 0);
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (e.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (n0 + j < g.Co) bias4[j] = e.bias[n0 + j];
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n0 < g.Co) {
+#pragma unroll 2
+    for (int ps_ = 0; ps_ < CPASS; ++ps_) {
+      const int row = cr + CRPP * ps_;
+      const int m = row0 + row;
+      if (m >= Mrows) break;
+      int pos = m;
+      if constexpr (TCONV) {
+        int n_, d_, h_, w_;
+        decode_row(m, cnt0, cnt1, cnt2, n_, d_, h_, w_);
+        const int od = ci.o0[0] + g.sd * d_, oh = ci.o0[1] + g.sh * h_, ow = ci.o0[2] + g.sw * w_;
+        pos = ((n_ * g.Do + od) * g.Ho + oh) * g.Wo + ow;
+      }
+      const float4 c = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
+      float v[4] = {c.x + bias4[0], c.y + bias4[1], c.z + bias4[2], c.w + bias4[3]};
+      const size_t o = (size_t)pos * e.ldc + e.col_off + n0;
+      const float sc = (e.residual && e.row_scale) ? e.row_scale[pos / e.rows_per_scale] : 1.f;
+      if (vec_out) {   // Co % 4 == 0 => the whole float4 is in range
+        if (e.act_grad_src) {
+          const float4 a = *reinterpret_cast<const float4*>(e.act_grad_src + o);
+          v[0] *= act_grad(a.x, e.act_grad_kind, e.slope); v[1] *= act_grad(a.y, e.act_grad_kind, e.slope);
+          v[2] *= act_grad(a.z, e.act_grad_kind, e.slope); v[3] *= act_grad(a.w, e.act_grad_kind, e.slope);
+        }
+        if (e.pre_act) *reinterpret_cast<float4*>(e.pre_act + o) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], e.act, e.slope);
+        if (e.residual) {
+          const float4 r = *reinterpret_cast<const float4*>(e.residual + (size_t)pos * e.ldr + n0);
+          v[0] = r.x + sc * v[0]; v[1] = r.y + sc * v[1]; v[2] = r.z + sc * v[2]; v[3] = r.w + sc * v[3];
+        }
+        *reinterpret_cast<float4*>(p.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (n0 + j < g.Co) {
+            float t = v[j];
+            if (e.act_grad_src) t *= act_grad(e.act_grad_src[o + j], e.act_grad_kind, e.slope);
+            if (e.pre_act) e.pre_act[o + j] = t;
+            t = apply_act(t, e.act, e.slope);
+            if (e.residual) t = e.residual[(size_t)pos * e.ldr + n0 + j] + sc * t;
+            p.y[o + j] = t;
+            s1[j] += t; s2[j] += t * t;
+          }
+        }
+      }
+    }
+  }
+  if (e.stats) {  // per-channel sum / sumsq of what was stored: lanes sharing a column group, then the 4 waves, then ONE
+                  // double atomic per column per workgroup into one of SV_BN_SLOTS accumulator slots (spreads contention)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int m = row0 + (wm * MT + mt) * 16 + lg * 4 + j;
-      int ps = -1;
-      if (m < Mrows) {
-        if constexpr (TCONV) {
-          int n_, d_, h_, w_;
-          decode_row(m, cnt0, cnt1, cnt2, n_, d_, h_, w_);
-          const int od = ci.o0[0] + g.sd * d_, oh = ci.o0[1] + g.sh * h_, ow = ci.o0[2] + g.sw * w_;
-          ps = ((n_ * g.Do + od) * g.Ho + oh) * g.Wo + ow;
-        } else {
-          ps = m;
-        }
-      }
-      pos[mt][j] = ps;
+#pragma unroll
+      for (int o = C4; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
     }
+    if ((lane / C4) == 0 || C4 >= 64) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = col0 + (wn * NT + nt) * 16 + lr;
-    const bool nok = n < g.Co;
-    const float bias = (nok && e.bias) ? e.bias[n] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ps = pos[mt][j];
-        if (ps >= 0 && nok) {
-          const size_t o = (size_t)ps * e.ldc + e.col_off + n;
-          float v = acc[mt][nt][j] + bias;
-          if (e.act_grad_src) v *= act_grad(e.act_grad_src[o], e.act_grad_kind, e.slope);
-          if (e.pre_act) e.pre_act[o] = v;
-          v = apply_act(v, e.act, e.slope);
-          if (e.residual) {
-            const float sc = e.row_scale ? e.row_scale[ps / e.rows_per_scale] : 1.f;
-            v = e.residual[(size_t)ps * e.ldr + n] + sc * v;
-          }
-          p.y[o] = v;
-          s1 += v; s2 += v * v;
-        }
-      }
+      for (int j = 0; j < 4; ++j) { red[(wave * BN + c4 * 4 + j) * 2] = s1[j]; red[(wave * BN + c4 * 4 + j) * 2 + 1] = s2[j]; }
     }
-    if (e.stats) {  // per-channel sum / sumsq of what was stored: reduce the 4 row groups, one atomic per column
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (lg == 0 && nok) {
-        atomicAdd(e.stats + n, (double)s1);
-        atomicAdd(e.stats + g.Co + n, (double)s2);
-      }
+    __syncthreads();
+    if (tid < BN && col0 + tid < g.Co) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+      double* st = e.stats + (size_t)(blockIdx.x % SV_BN_SLOTS) * 2 * g.Co;
+      atomicAdd(st + col0 + tid, (double)a);
+      atomicAdd(st + g.Co + col0 + tid, (double)b);
     }
   }
 }

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void lnl_apply_kernel(const float* __restrict_
 // backward pass 1: per-image sums of g and g*xhat (g = dy*mask*w) -> sums[I][2] (atomics)
 __global__ __launch_bounds__(256) void lnl_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ w, const float* __restrict__ meanrstd,
-                                                             float* __restrict__ sums, int L, float drop_p, uint32_t seed) {
+                                                             double* __restrict__ sums, int L, float drop_p, uint32_t seed) {
   __shared__ float sc[4];
   const int img = blockIdx.y;
   const float mean = meanrstd[img * 2], rstd = meanrstd[img * 2 + 1];
@@ -250,13 +250,13 @@ __global__ __launch_bounds__(256) void lnl_bwd_reduce_kernel(const float* __rest
   }
   s1 = block_sum<4>(s1, sc);
   s2 = block_sum<4>(s2, sc);
-  if (threadIdx.x == 0) { atomicAdd(sums + img * 2, s1); atomicAdd(sums + img * 2 + 1, s2); }
+  if (threadIdx.x == 0) { atomicAdd(sums + img * 2, (double)s1); atomicAdd(sums + img * 2 + 1, (double)s2); }
 }
 
 // backward pass 2: dx per element; dw/db accumulated over the images by the thread that owns element e
 __global__ __launch_bounds__(256) void lnl_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ w, const float* __restrict__ meanrstd,
-                                                            const float* __restrict__ sums, float* __restrict__ dx,
+                                                            const double* __restrict__ sums, float* __restrict__ dx,
                                                             float* __restrict__ dw, float* __restrict__ db, int L, int I,
                                                             float drop_p, uint32_t seed) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void lnl_bwd_apply_kernel(const float* __restr
     if (drop_p > 0.f) dd = uniform01(seed, (uint64_t)img * L + e) < drop_p ? 0.f : dd * keep_inv;
     const float xh = (x[(size_t)img * L + e] - mean) * rstd;
     const float g = dd * wv;
-    dx[(size_t)img * L + e] = rstd * (g - sums[img * 2] / L - xh * sums[img * 2 + 1] / L);
+    dx[(size_t)img * L + e] = (float)((double)rstd * ((double)g - sums[img * 2] / L - (double)xh * (sums[img * 2 + 1] / L)));
     aw += dd * xh; ab += dd;
   }
   dw[e] += aw; db[e] += ab;
@@ -307,8 +307,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   if (c >= C) return;
   float mean, var;
   if (training) {   // statistics in double: E[x^2]-mean^2 cancels badly in fp32 (torch's CPU path accumulates in double too)
-    const double m = sums[c] / count;
-    double v = sums[C + c] / count - m * m;
+    double t1 = 0.0, t2 = 0.0;
+    for (int sl = 0; sl < SV_BN_SLOTS; ++sl) { t1 += sums[(size_t)sl * 2 * C + c]; t2 += sums[(size_t)sl * 2 * C + C + c]; }
+    const double m = t1 / count;
+    double v = t2 / count - m * m;
     if (v < 0.0) v = 0.0;
     mean = (float)m; var = (float)v;
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
@@ -400,8 +402,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float rs = rstd[c];
     float o;
     if (training) {
-      const float xh = (x[(size_t)r * ldx + c] - mean[c]) * rs;
-      o = gamma[c] * rs * (d - (float)(sums[c] * invM) - xh * (float)(sums[C + c] * invM));
+      // double arithmetic for the mean-subtraction terms: sum_r dx must vanish to rounding, otherwise the residual is
+      // amplified by every later reduction over positions (torch's CPU kernel evaluates this expression in double too)
+      const double xh = ((double)x[(size_t)r * ldx + c] - (double)mean[c]) * (double)rs;
+      o = (float)((double)gamma[c] * (double)rs * ((double)d - sums[c] * invM - xh * (sums[C + c] * invM)));
     } else {
       o = d * gamma[c] * rs;
     }
@@ -463,10 +467,10 @@ extern "C" int sv_ln_image_fwd(const float* x, const float* w, const float* b, f
 }
 
 extern "C" int sv_ln_image_bwd(const float* dy, const float* x, const float* w, const float* meanrstd, float* dx, float* dw,
-                               float* db, float* sums_ws, int I, int L, float drop_p, uint32_t seed, void* stream) {
+                               float* db, double* sums_ws, int I, int L, float drop_p, uint32_t seed, void* stream) {
   SV_REQUIRE(dy && x && w && meanrstd && dx && dw && db && sums_ws && I > 0 && L > 0 && L % 4 == 0, "ln_image_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(sums_ws, 0, sizeof(float) * 2 * I, s);
+  (void)hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * I, s);
   int gx = cdiv(L, 1024); if (gx > 32) gx = 32;
   hipLaunchKernelGGL(lnl_bwd_reduce_kernel, dim3(gx, I), dim3(256), 0, s, dy, x, w, meanrstd, sums_ws, L, drop_p, seed);
   hipLaunchKernelGGL(lnl_bwd_apply_kernel, dim3(cdiv(L, 256)), dim3(256), 0, s, dy, x, w, meanrstd, sums_ws, dx, dw, db, L, I, drop_p, seed);

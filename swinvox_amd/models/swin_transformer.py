@@ -266,7 +266,7 @@ def swin_backward(st: SwinTransformer, tape, dfeats, I, grads):
             Cs, Hs = stage.dim, stage.res
             dxe = empty(I * Hs * Hs, Cs, like=xs)
             dwt, dbt = zeros(L, like=xs), zeros(L, like=xs)
-            sums = empty(2 * I, like=xs)
+            sums = torch.empty(2 * I, dtype=torch.float64, device=xs.device)
             call("sv_ln_image_bwd", ptr(dfeats[hi]), ptr(xs), ptr(wt), ptr(mr), ptr(dxe), ptr(dwt), ptr(dbt), ptr(sums), I, L, float(p), seed)
             ops.transpose(dwt, grads[ln.weight], 1, Hs * Hs, Cs)   # [HW,C] -> [C,HW]
             ops.transpose(dbt, grads[ln.bias], 1, Hs * Hs, Cs)

@@ -16,6 +16,7 @@ from . import hip
 from .hip import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, Epilogue, Geom, call, ptr  # noqa: F401
 
 _STATE = {"math": hip.MATH_F32}
+BN_SLOTS = 16   # SV_BN_SLOTS of include/swinvox_hip.h
 
 
 def set_math(mode: str) -> None:
@@ -204,7 +205,7 @@ class BatchNormState:
     def __init__(self, bn: torch.nn.Module, M: int, training: bool):
         self.bn, self.M, self.training, self.C = bn, M, training, bn.num_features
         dev = bn.weight.device
-        self.sums = torch.zeros(2 * self.C, dtype=torch.float64, device=dev) if training else None   # double accumulators
+        self.sums = torch.zeros(BN_SLOTS * 2 * self.C, dtype=torch.float64, device=dev) if training else None   # [slot][2C] doubles
         buf = empty(4 * self.C, device=dev)
         self.scale, self.shift, self.mean, self.rstd = buf[:self.C], buf[self.C:2 * self.C], buf[2 * self.C:3 * self.C], buf[3 * self.C:]
 

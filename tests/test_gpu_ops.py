@@ -117,11 +117,12 @@ def test_conv2d_fwd_dgrad_wgrad(dev, cin, cout, k, s, p, H):
     og = sp.out_grid((1, H, H))
     M = n * og[1] * og[2]
     out = ops.empty(M, cout, device=dev)
-    stats = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
+    stats = torch.zeros(ops.BN_SLOTS, 2 * cout, dtype=torch.float64, device=dev)
     sp.forward(xd, n, (1, H, H), sp.pack_fwd(wd), out, bias=b.to(dev), stats=stats)
     ref = cl(y.detach()).reshape(M, cout)
     assert rel(out, ref) < TOL
-    assert rel(stats[:cout], ref.sum(0)) < 1e-3 and rel(stats[cout:], (ref * ref).sum(0)) < 1e-3
+    st = stats.sum(0)
+    assert rel(st[:cout], ref.sum(0)) < 1e-3 and rel(st[cout:], (ref * ref).sum(0)) < 1e-3
     dyd = cl(dy).reshape(M, cout).to(dev)
     if s <= 2:   # the stride-4 patch embedding never needs a data gradient (its input is the image)
         dx = ops.empty(n * H * H, cin, device=dev)
@@ -252,7 +253,8 @@ def test_ln_image(dev):
     ws = ops.empty(int(hip.load().sv_ln_image_workspace_floats(I, L)), device=dev)
     call("sv_ln_image_fwd", ptr(xd), ptr(wt), ptr(bt), ptr(out), ptr(mr), ptr(ws), I, L, 1e-5, 0.0, 0)
     assert rel(out, y.permute(0, 2, 3, 1).reshape(I, L)) < TOL
-    dx, dw, db, sums = ops.empty(I, L, device=dev), ops.zeros(L, device=dev), ops.zeros(L, device=dev), ops.empty(2 * I, device=dev)
+    dx, dw, db = ops.empty(I, L, device=dev), ops.zeros(L, device=dev), ops.zeros(L, device=dev)
+    sums = torch.empty(2 * I, dtype=torch.float64, device=dev)
     dyd = dy.permute(0, 2, 3, 1).reshape(I, L).contiguous().to(dev)
     call("sv_ln_image_bwd", ptr(dyd), ptr(xd), ptr(wt), ptr(mr), ptr(dx), ptr(dw), ptr(db), ptr(sums), I, L, 0.0, 0)
     assert rel(dx, x.grad.reshape(I, L)) < TOL
