@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--math", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-views", type=int, default=4)
+    ap.add_argument("--cpu-views", type=int, default=2)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,6 +139,17 @@ def main():
         eng_n = sum(d["launches"] for d in eng)
         achieved = eng_fl / (eng_ms * 1e-3) / 1e12 if eng_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.math]
+        eng_bytes = sum(d["bytes"] for d in eng)
+        # HBM traffic per launch from the committed PMC passes of this same command (profiles/, rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 wide-read correction); null when not collected
+        traffic = None
+        try:
+            import glob
+            summ_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
+            pm = json.load(open(summ_files[-1])).get("pmc_traffic", {})
+            traffic = [v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if k.startswith("contraction engine")][0]
+        except Exception:
+            traffic = None
         out = {
             "metric": "views/sec fwd+bwd SwinVox-T 224^2, 32^3 voxel, n_views=8", "value": value, "unit": "views/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -150,7 +161,9 @@ def main():
                        "parallelism": f"dp{world} (sample-sharded, RCCL gradient all-reduce)" if world > 1 else "single GPU",
                        "math": "bf16 MFMA inputs, fp32 accumulate, fp32 activations/weights in HBM" if args.math == "bf16" else "exact fp32 MFMA"},
             "roofline": {"bound": "mfma", "kernel": "implicit-GEMM contraction engine (igemm_kernel / wgrad_kernel: all Linear/Conv/ConvTranspose fwd+dgrad+wgrad)",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": eng_bytes / max(eng_n, 1),
+                         "algorithmic_flops_per_launch": eng_fl / max(eng_n, 1),
                          "launches_per_step": eng_n / args.steps, "avg_launch_us": eng_ms * 1e3 / max(eng_n, 1),
                          "share_of_step_time": eng_ms * 1e-3 / dt},
             "kernels": {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["ms"] / args.steps,
@@ -159,7 +172,12 @@ def main():
             "model_flops_tflops_per_gpu": 3 * FWD_GFLOP_PER_VIEW.get(V, 19.4) * 1e9 * value / world / 1e12,
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_views, os.cpu_count() or 1)
+            # host share of a one-GPU box is 16 cores (os.cpu_count() reports the whole node): cap the thread pool there
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncpu = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(args.cpu_views, max(1, min(ncpu, 16)))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

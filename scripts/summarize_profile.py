@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 CSV output under gpurun_out/ into the small, tracked summaries under profiles/.
+
+  python scripts/summarize_profile.py --stats gpurun_out/prof_X --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write \
+         --tag r1 --steps-in-trace 4 --steps-in-pmc 2
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def family(name: str) -> str:
+    n = name.split("(")[0]
+    if "igemm_kernel" in n or "wgrad_kernel" in n:
+        return "contraction engine (igemm_kernel + wgrad_kernel)"
+    return n.replace("void ", "").strip()[-60:]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stats")
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("--tag", default="r1")
+    ap.add_argument("--steps-in-trace", type=int, default=4)
+    ap.add_argument("--steps-in-pmc", type=int, default=2)
+    a = ap.parse_args()
+    out = {"tag": a.tag}
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    if a.stats:
+        f = glob.glob(os.path.join(a.stats, "*", "*_kernel_stats.csv"))[0]
+        shutil.copy(f, os.path.join(ROOT, "profiles", f"{a.tag}_kernel_stats.csv"))
+        rows = list(csv.DictReader(open(f)))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        fam = collections.defaultdict(lambda: [0, 0.0])
+        for r in rows:
+            k = family(r["Name"])
+            fam[k][0] += int(r["Calls"])
+            fam[k][1] += float(r["TotalDurationNs"])
+        out["kernel_time"] = {"gpu_ms_per_step": tot / 1e6 / a.steps_in_trace, "families": {
+            k: {"launches_per_step": v[0] / a.steps_in_trace, "ms_per_step": v[1] / 1e6 / a.steps_in_trace,
+                "avg_launch_us": v[1] / 1e3 / v[0], "share": v[1] / tot}
+            for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])[:20]}}
+    if a.fetch and a.write:
+        def load(d):
+            f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+            agg = collections.defaultdict(lambda: [0, 0.0])
+            for r in csv.DictReader(open(f)):
+                k = family(r["Kernel_Name"])
+                agg[k][0] += 1
+                agg[k][1] += float(r["Counter_Value"])
+            return agg
+        fe, wr = load(a.fetch), load(a.write)
+        pm = {}
+        for k in sorted(fe, key=lambda k: -fe[k][1])[:14]:
+            n = fe[k][0]
+            pm[k] = {"launches_per_step": n / a.steps_in_pmc,
+                     "FETCH_SIZE_GB_per_step_raw": fe[k][1] / 1024 ** 2 / a.steps_in_pmc,
+                     "FETCH_GB_per_step_x2_gfx950_wide_read_correction": 2 * fe[k][1] / 1024 ** 2 / a.steps_in_pmc,
+                     "WRITE_SIZE_GB_per_step": wr.get(k, [0, 0.0])[1] / 1024 ** 2 / a.steps_in_pmc,
+                     "hbm_bytes_per_launch_corrected": (2 * fe[k][1] + wr.get(k, [0, 0.0])[1]) * 1024 / n}
+        out["pmc_traffic"] = pm
+    p = os.path.join(ROOT, "profiles", f"{a.tag}_summary.json")
+    json.dump(out, open(p, "w"), indent=1)
+    print("wrote", p)
+
+
+if __name__ == "__main__":
+    main()

@@ -674,7 +674,7 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, hi
     dim3 grid(cdiv(M, TileNarrow::BM), cdiv(Co, TileNarrow::BN), ncls);
     if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileNarrow>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileNarrow>), grid, dim3(256), 0, s, a);
-  } else if (Co % 128 == 0 && (long long)cdiv(M, 128) * (Co / 128) * ncls >= 512) {
+  } else if (false && Co > 64 && (long long)cdiv(M, 128) * cdiv(Co, 128) * ncls >= 256) {   // one pass over A per 128 output columns
     dim3 grid(cdiv(M, TileWide::BM), cdiv(Co, TileWide::BN), ncls);
     if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileWide>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileWide>), grid, dim3(256), 0, s, a);
@@ -687,6 +687,7 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, hi
 
 typedef Tile<2, 2, 4, 2> WTileDefault;   // 128 anchor channels x 64 (tap, gathered channel)
 typedef Tile<1, 4, 1, 2> WTileNarrow;    // 16 x 128 for <=16 anchor channels
+typedef Tile<2, 2, 4, 4> WTileWide;      // 128 x 128
 
 }  // namespace sv
 
@@ -760,7 +761,9 @@ extern "C" int sv_conv_wgrad(const float* anchor, int lda, const float* gathered
   a.out = a.direct ? dw : workspace;
   if (!a.direct) (void)hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)g->Co * Kout, s);
   const bool narrow = g->Co <= 16;
-  const int BMw = narrow ? WTileNarrow::BM : WTileDefault::BM, BNw = narrow ? WTileNarrow::BN : WTileDefault::BN;
+  const bool wide = false && !narrow && Kout >= 128;      // 128 x 128 tile: the anchor operand is re-read once per 128 (tap, channel) columns
+  const int BMw = narrow ? WTileNarrow::BM : WTileDefault::BM;
+  const int BNw = narrow ? WTileNarrow::BN : (wide ? WTileWide::BN : WTileDefault::BN);
   const int BKs = math == SV_MATH_BF16 ? 64 : 32;
   const int tiles = cdiv(g->Co, BMw) * cdiv(Kout, BNw);
   // enough splits to fill ~4 workgroups per CU, but at least 4 K-steps of work per split
@@ -778,6 +781,9 @@ extern "C" int sv_conv_wgrad(const float* anchor, int lda, const float* gathered
   if (narrow) {
     if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileNarrow>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wgrad_kernel<false, WTileNarrow>), grid, dim3(256), 0, s, a);
+  } else if (wide) {
+    if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileWide>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<false, WTileWide>), grid, dim3(256), 0, s, a);
   } else {
     if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileDefault>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wgrad_kernel<false, WTileDefault>), grid, dim3(256), 0, s, a);
