@@ -87,6 +87,17 @@ int sv_tconv_gather(const float* in, const float* w_packed, float* out, const sv
 size_t sv_conv_wgrad_workspace_floats(const sv_geom* g);
 int sv_conv_wgrad(const float* anchor, int lda, const float* gathered, float* dw, const sv_geom* g, int cg_valid,
                   float* workspace, int math, void* stream);
+/* LDS-halo MFMA stencils for 3x3x3 / stride 1 / pad 1 convolutions with <= 16 output channels per tile (merger.py:20-54),
+ * bf16 operands.  x: channels-last positions with row stride ldx, cin_load (multiple of 4) floats read per position,
+ * zero-extended to 16*groups channels; w_bf16: [16*ntiles16][27][16*groups] bf16 (forward: rows = output channels;
+ * data-gradient: rows = input channels, taps flipped).  Writes out[pos*ldc + col_off + n] for n < cout
+ * (= residual + value when residual != NULL); optional per-channel statistics as in sv_epilogue.stats. */
+int sv_stencil3_fwd(const float* x, int ldx, int cin_load, int groups, const void* w_bf16, int ntiles16,
+                    const float* bias, float* out, int ldc, int col_off, int cout, const float* residual, int ldr,
+                    double* stats, int I, int D, int H, int W, void* stream);
+/* dw[co][ci][27] += sum_vox dy[vox][co] * x[vox + tap][c]; memory channel c maps to ci = (c / c_stride)*c_valid + c % c_stride */
+int sv_stencil3_wgrad(const float* x, int ldx, int cin_load, int groups, const float* dy, int lddy, int cout_load,
+                      float* dw, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W, void* stream);
 /* dst[a][t][b] (b padded with zeros to bpad) from src[a][b][t]  (swap=0), or dst[b][t][a..apad] (swap=1) */
 int sv_pack_weight(const float* src, float* dst, int A, int B, int T, int swap, int pad_to, void* stream);
 /* per-column sum over rows: out[c] (+)= sum_r x[r*ld + c]  (bias gradients) */

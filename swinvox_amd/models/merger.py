@@ -1,8 +1,10 @@
 """Merger on HIP kernels; mirrors reference models/merger.py:9-107.
 
 forward(raw_features [B,V,9,32,32,32], coarse_volumes [B,V,32,32,32]) -> [B,32,32,32].
-The six 3x3x3 convolutions run on the implicit-GEMM engine over channels-last data padded 9 -> 12 channels
-(16-byte channel vectors); layers 1-4 write straight into the 4x12-wide concat buffer that layer 5 reads.
+The six 3x3x3 convolutions work on channels-last data padded 9 -> 12 channels (16-byte channel vectors); layers 1-4
+write straight into the 4x12-wide concat buffer that layer 5 reads.  Two kernel back-ends:
+  * set_math("bf16"): the LDS-halo MFMA stencils of csrc/stencil.hip (brick + halo staged once in LDS);
+  * set_math("f32") : the generic implicit-GEMM engine in exact fp32 (parity runs).
 """
 from __future__ import annotations
 
@@ -41,41 +43,93 @@ class Merger(HipModule):
         assert tuple(coarse_volumes.shape) == (raw_features.shape[0], raw_features.shape[1], 32, 32, 32)
         return self._run(raw_features, coarse_volumes)
 
+    # ---- per-layer contraction dispatch ---------------------------------------------------------------
+    def _layer(self, li):
+        return (self.layer1, self.layer2, self.layer3, self.layer4, self.layer5, self.layer6)[li]
+
+    def _spec(self, li):
+        return self._s14 if li < 4 else (self._s5 if li == 4 else self._s6)
+
     def _w5_padded(self):
         w5 = self.layer5[0].weight                       # [9,36,3,3,3] -> [9,48,27] with the concat column map
         wp = zeros(9, 48, 27, like=w5)
         wp[:, self._cat_cols] = w5.detach().reshape(9, 36, 27)
         return wp
 
+    def _stencil_pack(self, li, dgrad):
+        """bf16 weights for csrc/stencil.hip: forward [16][27][16G] (memory input channels), data-gradient
+        [16*NT][27][16] (rows = memory channels of the conv input, taps flipped).  Tiny tensors: a few torch index ops."""
+        w = self._layer(li)[0].weight.detach()
+        cout, cin = w.shape[0], w.shape[1]
+        cols = self._cat_cols if li == 4 else torch.arange(9, device=w.device)
+        wv = w.reshape(cout, cin, 27)
+        if not dgrad:
+            wp = zeros(16, 27, 48 if li == 4 else 16, like=w)
+            wp[:cout, :, cols] = wv.permute(0, 2, 1)
+        else:
+            wp = zeros(48 if li == 4 else 16, 27, 16, like=w)
+            wp[cols, :, :cout] = wv.flip(2).permute(1, 2, 0)
+        return wp.to(torch.bfloat16).contiguous()
+
+    def _conv_fwd(self, li, x, ldi, y, ldc, stats, w5p=None):
+        conv, I = self._layer(li)[0], x.shape[0] // VOX
+        if ops.get_math() == "bf16":
+            call("sv_stencil3_fwd", ptr(x), ldi, 48 if li == 4 else 12, 3 if li == 4 else 1, ptr(self._stencil_pack(li, False)), 1,
+                 ptr(conv.bias), ptr(y), ldc, 0, conv.out_channels, None, 0, ptr(stats), I, 32, 32, 32)
+        else:
+            sp = self._spec(li)
+            sp.forward(x, I, G, sp.pack_fwd(w5p if li == 4 else conv.weight), y, ldi=ldi, ldc=ldc, bias=conv.bias, stats=stats)
+
+    def _conv_dgrad(self, li, dy, lddy, dx, lddx, accumulate, w5p=None):
+        conv, I = self._layer(li)[0], dy.shape[0] // VOX
+        if ops.get_math() == "bf16":
+            call("sv_stencil3_fwd", ptr(dy), lddy, lddy if lddy <= 12 else 12, 1, ptr(self._stencil_pack(li, True)), 3 if li == 4 else 1,
+                 None, ptr(dx), lddx, 0, 48 if li == 4 else 9, ptr(dx) if accumulate else None, lddx, None, I, 32, 32, 32)
+        else:
+            sp = self._spec(li)
+            epi = dict(residual=dx, ldr=lddx) if accumulate else {}
+            sp.dgrad(dy, I, G, sp.pack_dgrad(w5p if li == 4 else conv.weight), dx, lddy=lddy, lddx=lddx, **epi)
+
+    def _conv_wgrad(self, li, dy, lddy, x, ldx, grads):
+        conv, I = self._layer(li)[0], dy.shape[0] // VOX
+        if ops.get_math() == "bf16":
+            call("sv_stencil3_wgrad", ptr(x), ldx, 48 if li == 4 else 12, 3 if li == 4 else 1, ptr(dy), lddy, lddy if lddy <= 12 else 12,
+                 ptr(grads[conv.weight]), conv.out_channels, conv.in_channels, 12 if li == 4 else 16, 9, I, 32, 32, 32)
+        elif li == 4:
+            dw5p = zeros(9, 48, 27, like=dy)
+            self._s5.wgrad(dy, x, I, G, dw5p, lddy=lddy, ldx=ldx)
+            grads[conv.weight].view(9, 36, 27).copy_(dw5p[:, self._cat_cols])
+        else:
+            self._spec(li).wgrad(dy, x, I, G, grads[conv.weight], lddy=lddy, ldx=ldx)
+
+    # ---- forward / backward chains -------------------------------------------------------------------------
     def _fwd(self, raw, vol, save):
         B, V = raw.shape[:2]
-        I, M, tr, sl = B * V, B * V * VOX, self.training, self._slope
+        M, tr, sl = B * V * VOX, self.training, self._slope
         x12 = as_channels_last12(raw)
         vol = vol.contiguous()
         cat = zeros(M, 48, like=vol)
+        w5p = self._w5_padded() if ops.get_math() != "bf16" else None
         ctx14, xin, ldi = [], x12, 12
-        for k, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
-            conv, bn = layer[0], layer[1]
+        for k in range(4):
+            bn = self._layer(k)[1]
             y = empty(M, 9, like=vol)
             st = BatchNormState(bn, M, tr)
-            self._s14.forward(xin, I, G, self._s14.pack_fwd(conv.weight), y, ldi=ldi, ldc=9, bias=conv.bias, stats=st.sums)
+            self._conv_fwd(k, xin, ldi, y, 9, st.sums)
             st.finalize()
             z = cat[:, 12 * k:]
             st.apply(y, 9, z, 48, ACT_LRELU, sl)
             ctx14.append((xin, ldi, y, z, st))
             xin, ldi = z, 48
-        conv5, bn5 = self.layer5[0], self.layer5[1]
-        w5p = self._w5_padded()
         y5 = empty(M, 9, like=vol)
-        st5 = BatchNormState(bn5, M, tr)
-        self._s5.forward(cat, I, G, self._s5.pack_fwd(w5p), y5, ldi=48, ldc=9, bias=conv5.bias, stats=st5.sums)
+        st5 = BatchNormState(self.layer5[1], M, tr)
+        self._conv_fwd(4, cat, 48, y5, 9, st5.sums, w5p)
         st5.finalize()
         z5 = zeros(M, 12, like=vol)
         st5.apply(y5, 9, z5, 12, ACT_LRELU, sl)
-        conv6, bn6 = self.layer6[0], self.layer6[1]
         y6 = empty(M, 1, like=vol)
-        st6 = BatchNormState(bn6, M, tr)
-        self._s6.forward(z5, I, G, self._s6.pack_fwd(conv6.weight), y6, ldi=12, ldc=1, bias=conv6.bias, stats=st6.sums)
+        st6 = BatchNormState(self.layer6[1], M, tr)
+        self._conv_fwd(5, z5, 12, y6, 1, st6.sums)
         st6.finalize()
         wl = empty(M, 1, like=vol)
         st6.apply(y6, 1, wl, 1, ACT_LRELU, sl)
@@ -86,7 +140,7 @@ class Merger(HipModule):
 
     def _bwd(self, tape, grads, in_needs, dout):
         B, V, x12, vol, cat, ctx14, w5p, y5, st5, z5, y6, st6, wl, out = tape
-        I, M, sl = B * V, B * V * VOX, self._slope
+        M, sl = B * V * VOX, self._slope
         dout = dout.contiguous()
         dwl = empty(M, 1, like=vol)
         dvol = empty(B, V, 32, 32, 32, like=vol)
@@ -96,38 +150,31 @@ class Merger(HipModule):
         dy6 = zeros(M, 4, like=vol)
         st6.backward(dwl, 1, wl, 1, y6, 1, dy6, 4, grads[bn6.weight], grads[bn6.bias], ACT_LRELU, sl)
         ops.colsum(dy6, M, 1, 4, grads[conv6.bias])
-        self._s6.wgrad(dy6, z5, I, G, grads[conv6.weight], lddy=4, ldx=12)
+        self._conv_wgrad(5, dy6, 4, z5, 12, grads)
         dz5 = zeros(M, 12, like=vol)
-        self._s6.dgrad(dy6, I, G, self._s6.pack_dgrad(conv6.weight), dz5, lddy=4, lddx=12)
+        self._conv_dgrad(5, dy6, 4, dz5, 12, False)
         # ---- layer 5
         conv5, bn5 = self.layer5[0], self.layer5[1]
         dy5 = zeros(M, 12, like=vol)
         st5.backward(dz5, 12, z5, 12, y5, 9, dy5, 12, grads[bn5.weight], grads[bn5.bias], ACT_LRELU, sl)
         ops.colsum(dy5, M, 9, 12, grads[conv5.bias])
-        dw5p = zeros(9, 48, 27, like=vol)
-        self._s5.wgrad(dy5, cat, I, G, dw5p, lddy=12, ldx=48)
-        grads[conv5.weight].view(9, 36, 27).copy_(dw5p[:, self._cat_cols])
-        dcat = zeros(M, 48, like=vol)
-        # data-gradient wrt the 48-wide concat buffer: produce all 48 columns (pad columns get zero weights)
-        s5d = ConvSpec.conv3d(48, 9, 3, 1, 1, cin_mem=48, cout_mem=12)
-        s5d.dgrad(dy5, I, G, s5d.pack_dgrad(w5p), dcat, lddy=12, lddx=48)
+        self._conv_wgrad(4, dy5, 12, cat, 48, grads)
+        dcat = zeros(M, 48, like=vol)   # data-gradient wrt the 48-wide concat buffer (pad columns receive zero weights)
+        self._conv_dgrad(4, dy5, 12, dcat, 48, False, w5p)
         # ---- layers 4..1: z_k feeds layer k+1 and the concat -> gradients add up in dcat[:, 12k:12k+9]
         dx = None
         for k in (3, 2, 1, 0):
-            layer = (self.layer1, self.layer2, self.layer3, self.layer4)[k]
-            conv, bn = layer[0], layer[1]
+            conv, bn = self._layer(k)[0], self._layer(k)[1]
             xin, ldi, y, z, st = ctx14[k]
             dzk = dcat[:, 12 * k:]
             dy = zeros(M, 12, like=vol)
             st.backward(dzk, 48, z, 48, y, 9, dy, 12, grads[bn.weight], grads[bn.bias], ACT_LRELU, sl)
             ops.colsum(dy, M, 9, 12, grads[conv.bias])
-            self._s14.wgrad(dy, xin, I, G, grads[conv.weight], lddy=12, ldx=ldi)
-            wd = self._s14.pack_dgrad(conv.weight)
+            self._conv_wgrad(k, dy, 12, xin, ldi, grads)
             if k > 0:   # accumulate into the previous layer's slot of dcat
-                prev = dcat[:, 12 * (k - 1):]
-                self._s14.dgrad(dy, I, G, wd, prev, lddy=12, lddx=48, residual=prev, ldr=48)
+                self._conv_dgrad(k, dy, 12, dcat[:, 12 * (k - 1):], 48, True)
             else:
                 dx = zeros(M, 12, like=vol)
-                self._s14.dgrad(dy, I, G, wd, dx, lddy=12, lddx=12)
+                self._conv_dgrad(k, dy, 12, dx, 12, False)
         draw = raw_view(dx, B, V) if in_needs[0] else None
         return (draw, dvol if in_needs[1] else None)

@@ -240,3 +240,54 @@ def test_single_stage_config(dev):
     x = synth_images(1, 1, 5)
     with torch.no_grad():
         assert rel(p(x.to(dev)), o(x)) < 1e-3
+
+
+def test_bf16_math(dev, nets):
+    """set_math("bf16") (MFMA bf16 operands, fp32 accumulate; LDS-halo stencils in the merger).
+    Tail modules (well conditioned): forward within 2e-2 of the fp32 oracle on the oracle's own inputs, gradients within
+    30 % L1 (train-mode BatchNorm over 4 images amplifies bf16 rounding in the backward).  Encoder: this weight set amplifies bf16 rounding (the CPU oracle under torch.autocast(bfloat16) is itself
+    ~40 % off its fp32 result), so the HIP error is bounded by 1.5x that CPU-bf16 deviation; gradients must be finite."""
+    import copy
+    onets, _ = nets
+    ocp = [copy.deepcopy(n).train() for n in onets]
+    no_stochastic(ocp)
+    pcfg = S.default_cfg()
+    pn = [Encoder(pcfg), Decoder(pcfg), Merger(pcfg), Refiner(pcfg)]
+    for p, o in zip(pn, ocp):
+        p.load_state_dict(o.state_dict()); p.to(dev).train(); p.stochastic = False
+    x, gt = synth_images(2, 2, 44), synth_gt(2, 44)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    oc2 = [copy.deepcopy(n) for n in ocp]
+    with torch.no_grad():
+        f_o = oc2[0](x)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            f_ob = copy.deepcopy(ocp[0])(x).float()
+    cpu_bf16_dev = rel(f_ob, f_o)
+    feat = f_o.clone().requires_grad_(True)
+    raw_o, vol_o = ocp[1](feat)
+    mer_o = ocp[2](raw_o, vol_o)
+    ref_o = ocp[3](mer_o)
+    (bce(mer_o, gt) + bce(ref_o, gt)).backward()
+    ops.set_math("bf16")
+    try:
+        f_p = pn[0](x.to(dev))
+        f_p.square().mean().backward()
+        featd = f_o.clone().to(dev).requires_grad_(True)
+        raw, vol = pn[1](featd)
+        merged = pn[2](raw, vol)
+        refined = pn[3](merged)
+        (bce(merged, gt.to(dev)) + bce(refined, gt.to(dev))).backward()
+    finally:
+        ops.set_math("f32")
+    assert rel(f_p, f_o) < 1.5 * cpu_bf16_dev + 2e-2, (rel(f_p, f_o), cpu_bf16_dev)
+    assert rel(vol, vol_o) < 2e-2 and rel(merged, mer_o) < 2e-2 and rel(refined, ref_o) < 2e-2
+    iou_p, iou_o = np.array(O.iou_at_thresholds(refined.detach().cpu(), gt)), np.array(O.iou_at_thresholds(ref_o.detach(), gt))
+    assert np.abs(iou_p - iou_o).max() < 1e-2
+    for k, a in pn[0].named_parameters():
+        assert bool(torch.isfinite(a.grad).all()), k
+    assert float((featd.grad.cpu() - feat.grad).abs().sum() / feat.grad.abs().sum()) < 0.3
+    for p, o in ((pn[1], ocp[1]), (pn[2], ocp[2]), (pn[3], ocp[3])):
+        for (k, a), (_, b) in zip(p.named_parameters(), o.named_parameters()):
+            if float(b.grad.abs().max()) > 1e-8:
+                l1 = float((a.grad.cpu() - b.grad).abs().sum() / b.grad.abs().sum())
+                assert l1 < 0.3, (type(p).__name__, k, l1)

@@ -484,3 +484,45 @@ def test_error_convention(dev):
         ops.layernorm_fwd(x, x, x, 10, 10)          # C=10 not a multiple of 4
     with pytest.raises(RuntimeError, match="window_attention"):
         call("sv_window_attention_fwd", ptr(x), ptr(x), ptr(x), 1, 10, 10, 96, 3, 0, 0)
+
+
+# ------------------------------------------------------------------------------------------------ LDS-halo MFMA stencils
+@pytest.mark.parametrize("cin,cout,groups", [(9, 9, 1), (9, 1, 1), (36, 9, 3)])
+def test_stencil3_fwd_dgrad_wgrad(dev, cin, cout, groups):
+    """csrc/stencil.hip vs torch conv3d on bf16-rounded operands (fp32 accumulate)."""
+    g = torch.Generator().manual_seed(cin + cout)
+    n, D = 2, 32
+    bf = lambda t: t.bfloat16().float()
+    x = bf(torch.randn(n, cin, D, D, D, generator=g)).requires_grad_(True)
+    w = bf(torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(cin * 27)).requires_grad_(True)
+    b = torch.randn(cout, generator=g)
+    y = F.conv3d(x, w, b, padding=1)
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    M = n * D ** 3
+    cmem = 16 * groups if groups == 1 else 48
+    ld = 12 if groups == 1 else 48
+    cols = torch.arange(cin) if groups == 1 else torch.tensor([12 * k + j for k in range(4) for j in range(9)])
+    xm = torch.zeros(M, ld); xm[:, cols] = cl(x.detach()).reshape(M, cin)
+    wf = torch.zeros(16, 27, cmem); wf[:cout][:, :, cols] = w.detach().reshape(cout, cin, 27).permute(0, 2, 1)
+    xd, wfd, bd = xm.to(dev), wf.to(dev).bfloat16().contiguous(), b.to(dev)
+    out = ops.zeros(M, 12, device=dev)
+    stats = torch.zeros(ops.BN_SLOTS, 2 * cout, dtype=torch.float64, device=dev)
+    call("sv_stencil3_fwd", ptr(xd), ld, ld, groups, ptr(wfd), 1, ptr(bd), ptr(out), 12, 0, cout, None, 0, ptr(stats), n, D, D, D)
+    ref = cl(y.detach()).reshape(M, cout)
+    assert rel(out[:, :cout], ref) < 2e-5
+    st = stats.sum(0)
+    assert rel(st[:cout], ref.double().sum(0)) < 1e-5 and rel(st[cout:], (ref.double() ** 2).sum(0)) < 1e-5
+    # data gradient = the same kernel with flipped / transposed weights (rows = memory channels of the conv input)
+    nt = 1 if groups == 1 else 3
+    wd = torch.zeros(16 * nt, 27, 16); wd[cols, :, :cout] = w.detach().reshape(cout, cin, 27).flip(2).permute(1, 2, 0)
+    dym = torch.zeros(M, 12); dym[:, :cout] = cl(dy).reshape(M, cout)
+    dyd, wdd = dym.to(dev), wd.to(dev).bfloat16().contiguous()
+    base = torch.randn(M, ld, generator=g)
+    dx = base.clone().to(dev)
+    call("sv_stencil3_fwd", ptr(dyd), 12, 12, 1, ptr(wdd), nt, None, ptr(dx), ld, 0, ld if groups == 3 else 9, ptr(dx), ld, None, n, D, D, D)
+    assert rel((dx.cpu() - base)[:, cols], cl(x.grad).reshape(M, cin)) < 2e-5
+    # weight gradient (bf16 operands, fp32 atomics)
+    dw = ops.zeros(cout, cin, 3, 3, 3, device=dev)
+    call("sv_stencil3_wgrad", ptr(xd), ld, ld, groups, ptr(dyd), 12, 12, ptr(dw), cout, cin, 16 if groups == 1 else 12, 9, n, D, D, D)
+    assert rel(dw, w.grad) < 2e-4
