@@ -54,9 +54,11 @@ template <> struct Cfg<true> {
 template <int WM_, int WN_, int MT_, int NT_> struct Tile {
   static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_;
   static constexpr int BM = WM_ * MT_ * 16, BN = WN_ * NT_ * 16;
+  static constexpr int NW = WM_ * WN_, NTHR = NW * 64;
 };
 typedef Tile<2, 2, 4, 2> TileDefault;   // 128 x 64
-typedef Tile<2, 2, 4, 4> TileWide;      // 128 x 128
+typedef Tile<2, 2, 4, 4> TileWide;      // 128 x 128, 4 waves (register-heavy: measured slower, kept for reference)
+typedef Tile<2, 4, 4, 2> TileBig;       // 128 x 128, 8 waves (512 threads): halves the A re-reads of TileDefault at equal registers
 typedef Tile<4, 1, 2, 1> TileNarrow;    // 128 x 16
 
 __device__ __forceinline__ void store4(float* dst, float4 v) { *reinterpret_cast<float4*>(dst) = v; }
@@ -163,18 +165,19 @@ __device__ __forceinline__ void decode_row(int m, int c0, int c1, int c2, int& n
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------------
 template <bool BF16, bool TCONV, typename TL>
-__global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
+__global__ __launch_bounds__(TL::NTHR) void igemm_kernel(const IGemmArgs p) {
   typedef typename Cfg<BF16>::T LT;
   constexpr int BK = Cfg<BF16>::BK, LD = BK + Cfg<BF16>::PAD;
   constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT;
   constexpr int TPR = BK / 4;          // threads per tile row (one float4 each)
-  constexpr int RPP = 256 / TPR;       // rows per pass
+  constexpr int NTHR = TL::NTHR, NW = TL::NW;
+  constexpr int RPP = NTHR / TPR;      // rows per pass
   constexpr int NA = BM / RPP;
   constexpr int NB = (BN + RPP - 1) / RPP;
   constexpr int LDC = BN + 4;          // fp32 staging tile of the epilogue (aliases the operand tiles)
   constexpr int AB_BYTES = (BM + BN) * LD * (int)sizeof(LT), C_BYTES = BM * LDC * 4;
   __shared__ __attribute__((aligned(16))) char smem[AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES];
-  __shared__ float red[4 * BN * 2];
+  __shared__ float red[NW * BN * 2];
   LT* As = reinterpret_cast<LT*>(smem);
   LT* Bs = As + BM * LD;
   float* Cs = reinterpret_cast<float*>(smem);
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
           Cs[((wm * MT + mt) * 16 + lg * 4 + j) * LDC + (wn * NT + nt) * 16 + lr] = acc[mt][nt][j];
   }
   __syncthreads();
-  constexpr int C4 = BN / 4, CRPP = 256 / C4, CPASS = BM / CRPP;
+  constexpr int C4 = BN / 4, CRPP = NTHR / C4, CPASS = BM / CRPP;
   const int c4 = tid % C4, cr = tid / C4;
   const int n0 = col0 + c4 * 4;
   const bool vec_out = ((e.ldc | e.col_off | g.Co) & 3) == 0 && (!e.residual || (e.ldr & 3) == 0);
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs p) {
     if (tid < BN && col0 + tid < g.Co) {
       float a = 0.f, b = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+      for (int w = 0; w < NW; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
       double* st = e.stats + (size_t)(blockIdx.x % SV_BN_SLOTS) * 2 * g.Co;
       atomicAdd(st + col0 + tid, (double)a);
       atomicAdd(st + g.Co + col0 + tid, (double)b);
@@ -437,13 +440,14 @@ struct WGradArgs {
 };
 
 template <bool BF16, typename TL>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs p) {
+__global__ __launch_bounds__(TL::NTHR) void wgrad_kernel(const WGradArgs p) {
   typedef typename Cfg<BF16>::T LT;
   constexpr int BK = Cfg<BF16>::BK, PAD = Cfg<BF16>::PAD;
   constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT;
   constexpr int LDA = BM + PAD, LDB = BN + PAD;
-  constexpr int A4 = BM / 4, A_RPP = 256 / A4, A_PASS = (BK + A_RPP - 1) / A_RPP;   // float4 columns / rows per pass / passes
-  constexpr int B4 = BN / 4, B_RPP = 256 / B4, B_PASS = (BK + B_RPP - 1) / B_RPP;
+  constexpr int NTHR = TL::NTHR;
+  constexpr int A4 = BM / 4, A_RPP = NTHR / A4, A_PASS = (BK + A_RPP - 1) / A_RPP;   // float4 columns / rows per pass / passes
+  constexpr int B4 = BN / 4, B_RPP = NTHR / B4, B_PASS = (BK + B_RPP - 1) / B_RPP;
   __shared__ __attribute__((aligned(16))) LT As[BK * LDA];  // [r][ca]
   __shared__ __attribute__((aligned(16))) LT Bs[BK * LDB];  // [r][k_out]
 
@@ -674,10 +678,10 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, hi
     dim3 grid(cdiv(M, TileNarrow::BM), cdiv(Co, TileNarrow::BN), ncls);
     if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileNarrow>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileNarrow>), grid, dim3(256), 0, s, a);
-  } else if (false && Co > 64 && (long long)cdiv(M, 128) * cdiv(Co, 128) * ncls >= 256) {   // one pass over A per 128 output columns
-    dim3 grid(cdiv(M, TileWide::BM), cdiv(Co, TileWide::BN), ncls);
-    if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileWide>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileWide>), grid, dim3(256), 0, s, a);
+  } else if (Co > 64 && (long long)cdiv(M, 128) * cdiv(Co, 128) * ncls >= 384) {   // 8-wave 128x128: one pass over A per 128 output columns
+    dim3 grid(cdiv(M, TileBig::BM), cdiv(Co, TileBig::BN), ncls);
+    if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileBig>), grid, dim3(TileBig::NTHR), 0, s, a);
+    else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileBig>), grid, dim3(TileBig::NTHR), 0, s, a);
   } else {
     dim3 grid(cdiv(M, TileDefault::BM), cdiv(Co, TileDefault::BN), ncls);
     if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileDefault>), grid, dim3(256), 0, s, a);
@@ -687,7 +691,7 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, hi
 
 typedef Tile<2, 2, 4, 2> WTileDefault;   // 128 anchor channels x 64 (tap, gathered channel)
 typedef Tile<1, 4, 1, 2> WTileNarrow;    // 16 x 128 for <=16 anchor channels
-typedef Tile<2, 2, 4, 4> WTileWide;      // 128 x 128
+typedef Tile<2, 4, 4, 2> WTileWide;      // 128 x 128, 8 waves
 
 }  // namespace sv
 
@@ -761,7 +765,7 @@ extern "C" int sv_conv_wgrad(const float* anchor, int lda, const float* gathered
   a.out = a.direct ? dw : workspace;
   if (!a.direct) (void)hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)g->Co * Kout, s);
   const bool narrow = g->Co <= 16;
-  const bool wide = false && !narrow && Kout >= 128;      // 128 x 128 tile: the anchor operand is re-read once per 128 (tap, channel) columns
+  const bool wide = !narrow && Kout >= 128;      // 128 x 128 tile: the anchor operand is re-read once per 128 (tap, channel) columns
   const int BMw = narrow ? WTileNarrow::BM : WTileDefault::BM;
   const int BNw = narrow ? WTileNarrow::BN : (wide ? WTileWide::BN : WTileDefault::BN);
   const int BKs = math == SV_MATH_BF16 ? 64 : 32;
@@ -782,8 +786,8 @@ extern "C" int sv_conv_wgrad(const float* anchor, int lda, const float* gathered
     if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileNarrow>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wgrad_kernel<false, WTileNarrow>), grid, dim3(256), 0, s, a);
   } else if (wide) {
-    if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileWide>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<false, WTileWide>), grid, dim3(256), 0, s, a);
+    if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileWide>), grid, dim3(WTileWide::NTHR), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<false, WTileWide>), grid, dim3(WTileWide::NTHR), 0, s, a);
   } else {
     if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileDefault>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wgrad_kernel<false, WTileDefault>), grid, dim3(256), 0, s, a);
