@@ -141,7 +141,7 @@ int sv_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const float* x
 int sv_window_attention_fwd(const float* qkv, const float* table, float* out, int I, int H, int W, int C, int heads,
                             int shift, int math, void* stream);
 int sv_window_attention_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable,
-                            int I, int H, int W, int C, int heads, int shift, void* stream);
+                            int I, int H, int W, int C, int heads, int shift, int math, void* stream);
 int sv_cross_view_attention_fwd(const float* qkv, float* out, int B, int V, int P, int R, int heads, void* stream);
 int sv_cross_view_attention_bwd(const float* qkv, const float* dout, float* dqkv, int B, int V, int P, int R, int heads,
                                 void* stream);

@@ -370,7 +370,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     const float mu = mean[c], rs = rstd[c];
-    for (long long r = r0 + rl; r < r1e; r += 4) {
+    long long r = r0 + rl;
+    for (; r + 12 < r1e; r += 16) {   // 4 rows in flight per thread (independent loads), then the serial tail
+      float d[4], xv[4], zv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        d[u] = dz[(size_t)(r + 4 * u) * lddz + c];
+        xv[u] = x[(size_t)(r + 4 * u) * ldx + c];
+        zv[u] = act != SV_ACT_NONE ? z[(size_t)(r + 4 * u) * ldz + c] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (act != SV_ACT_NONE) d[u] *= (zv[u] > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
+        s1 += (double)d[u]; s2 += (double)(d[u] * (xv[u] - mu) * rs);
+      }
+    }
+    for (; r < r1e; r += 4) {
       float d = dz[(size_t)r * lddz + c];
       if (act != SV_ACT_NONE) d *= (z[(size_t)r * ldz + c] > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
       s1 += (double)d; s2 += (double)(d * (x[(size_t)r * ldx + c] - mu) * rs);

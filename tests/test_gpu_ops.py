@@ -329,8 +329,12 @@ def test_window_attention(dev, H, heads, shift):
     call("sv_window_attention_fwd", ptr(qd), ptr(td), ptr(out16), I, H, H, Cd, heads, shift, hip.MATH_BF16)
     assert rel(out16, ref) < 2e-2
     dqkv, dt = ops.empty(I * H * H, 3 * Cd, device=dev), ops.zeros(169, heads, device=dev)
-    call("sv_window_attention_bwd", ptr(qd), ptr(td), ptr(keep(do.to(dev))), ptr(dqkv), ptr(dt), I, H, H, Cd, heads, shift)
+    dod = do.to(dev)
+    call("sv_window_attention_bwd", ptr(qd), ptr(td), ptr(dod), ptr(dqkv), ptr(dt), I, H, H, Cd, heads, shift, hip.MATH_F32)
     assert rel(dqkv, qkv.grad) < TOL and rel(dt, table.grad) < TOL
+    dqkv16, dt16 = ops.empty(I * H * H, 3 * Cd, device=dev), ops.zeros(169, heads, device=dev)
+    call("sv_window_attention_bwd", ptr(qd), ptr(td), ptr(dod), ptr(dqkv16), ptr(dt16), I, H, H, Cd, heads, shift, hip.MATH_BF16)
+    assert rel(dqkv16, qkv.grad) < 3e-2 and rel(dt16, table.grad) < 3e-2
 
 
 @pytest.mark.parametrize("V", [1, 3, 8])
