@@ -52,6 +52,8 @@ def test_gating_without_merger_and_refiner(dev):
     cfg = S.default_cfg()
     cfg.NETWORK.USE_MERGER, cfg.NETWORK.USE_REFINER = False, False
     nets = _nets(dev, cfg)
+    for n in nets:
+        n.stochastic = False        # dropout / drop-path off so the forward can be repeated
     g = torch.Generator().manual_seed(4)
     x = (0.5 * torch.randn(1, 3, 3, 224, 224, generator=g)).to(dev)
     gt = (torch.rand(1, 32, 32, 32, generator=g) < 0.1).float().to(dev)
