@@ -63,12 +63,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # rehearsal hooks for a one-GPU box: SV_FORCE_DEVICE pins every rank to one card, SV_DIST_BACKEND=gloo replaces RCCL
+    local = int(os.environ.get("SV_FORCE_DEVICE", local))
+    backend = os.environ.get("SV_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     import swinvox_amd as S
     from swinvox_amd import hip

@@ -86,7 +86,7 @@ int sv_tconv_gather(const float* in, const float* w_packed, float* out, const sv
  * (sv_conv_wgrad_workspace_floats(g) floats, caller-owned, contents destroyed) and folded into dw by a second kernel. */
 size_t sv_conv_wgrad_workspace_floats(const sv_geom* g);
 int sv_conv_wgrad(const float* anchor, int lda, const float* gathered, float* dw, const sv_geom* g, int cg_valid,
-                  float* workspace, int math, void* stream);
+                  float* workspace, float* dbias /* optional: dbias[ca] += sum_r anchor[r, ca] */, int math, void* stream);
 /* LDS-halo MFMA stencils for 3x3x3 / stride 1 / pad 1 convolutions with <= 16 output channels per tile (merger.py:20-54),
  * bf16 operands.  x: channels-last positions with row stride ldx, cin_load (multiple of 4) floats read per position,
  * zero-extended to 16*groups channels; w_bf16: [16*ntiles16][27][16*groups] bf16 (forward: rows = output channels;

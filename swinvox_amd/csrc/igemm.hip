@@ -153,6 +153,14 @@ __device__ __forceinline__ void mma_slab_km(const typename Cfg<BF16>::T* As, con
   }
 }
 
+// XCD-aware, bijective remap of the linear workgroup id: blocks are dealt round-robin over the 8 XCDs (b and b+8 share an
+// L2), so give every XCD one CONTIGUOUS chunk of the logical tile order -> tiles that share an operand panel (all output-
+// column tiles of one activation row panel; all (channel, tap) tiles of one position range in wgrad) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // row index -> (n, d, h, w) of a grid; spatial == 1 (Linear) needs no division at all
 __device__ __forceinline__ void decode_row(int m, int c0, int c1, int c2, int& n_, int& d_, int& h_, int& w_) {
   if (c0 * c1 * c2 == 1) { n_ = m; d_ = h_ = w_ = 0; return; }
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(TL::NTHR) void igemm_kernel(const IGemmArgs p) {
   int cnt0, cnt1, cnt2, T0, T1, T2;
   ClassInfo ci;
   if constexpr (TCONV) {
-    ci = p.cls[blockIdx.z];
+    ci = p.cls[blockIdx.y];
     cnt0 = ci.cnt[0]; cnt1 = ci.cnt[1]; cnt2 = ci.cnt[2];
     T0 = ci.T[0]; T1 = ci.T[1]; T2 = ci.T[2];
   } else {
@@ -198,9 +206,12 @@ __global__ __launch_bounds__(TL::NTHR) void igemm_kernel(const IGemmArgs p) {
   }
   const int Mrows = g.N * cnt0 * cnt1 * cnt2;
   const int K = T0 * T1 * T2 * g.Ci;
-  const int row0 = blockIdx.x * BM;
+  // logical tile order: output-column tile fastest (the column tiles of one row panel run together and share A in L2)
+  const int tiles_n = (g.Co + BN - 1) / BN;
+  const int tlin = xcd_remap(blockIdx.x, gridDim.x);
+  const int row0 = (tlin / tiles_n) * BM;
   if (row0 >= Mrows) return;
-  const int col0 = blockIdx.y * BN;
+  const int col0 = (tlin % tiles_n) * BN;
 
   // ---- per-thread loader state -----------------------------------------------------------------
   const int kq = (tid % TPR) * 4;
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(TL::NTHR) void igemm_kernel(const IGemmArgs p) {
       float a = 0.f, b = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
-      double* st = e.stats + (size_t)(blockIdx.x % SV_BN_SLOTS) * 2 * g.Co;
+      double* st = e.stats + (size_t)((row0 / BM) % SV_BN_SLOTS) * 2 * g.Co;
       atomicAdd(st + col0 + tid, (double)a);
       atomicAdd(st + g.Co + col0 + tid, (double)b);
     }
@@ -437,6 +448,7 @@ __global__ __launch_bounds__(TL::NTHR) void igemm_kernel(const IGemmArgs p) {
 struct WGradArgs {
   const float* anchor; int lda; const float* gathered; float* out;   // out = dw (taps == 1) or the packed workspace
   Geom g; int cg_valid; int rows_per_split; int Mrows; int direct;
+  float* dbias;     // optional: dbias[ca] += sum_r anchor[r, ca] (bias gradient), folded into the k_out-tile-0 workgroups
 };
 
 template <bool BF16, typename TL>
@@ -456,8 +468,10 @@ __global__ __launch_bounds__(TL::NTHR) void wgrad_kernel(const WGradArgs p) {
   const int wm = wave / TL::WN, wn = wave % TL::WN;
   const int taps = g.kd * g.kh * g.kw;
   const int Kout = taps * g.Ci;
-  const int ca0 = blockIdx.x * BM, ko0 = blockIdx.y * BN;
-  const int r_begin = blockIdx.z * p.rows_per_split;
+  const int gx = (g.Co + BM - 1) / BM, gy = (Kout + BN - 1) / BN;
+  const int tlin = xcd_remap(blockIdx.x, gridDim.x);          // (ca tile fastest, then k_out tile, then position split)
+  const int ca0 = (tlin % gx) * BM, ko0 = ((tlin / gx) % gy) * BN;
+  const int r_begin = (tlin / (gx * gy)) * p.rows_per_split;
   int r_end = r_begin + p.rows_per_split;
   if (r_end > p.Mrows) r_end = p.Mrows;
   if (r_begin >= r_end) return;
@@ -568,6 +582,8 @@ __global__ __launch_bounds__(TL::NTHR) void wgrad_kernel(const WGradArgs p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const bool do_bias = p.dbias != nullptr && ko0 == 0;
+  float bsum = 0.f;
   load_tile();
   store_tile();
   __syncthreads();
@@ -575,6 +591,12 @@ __global__ __launch_bounds__(TL::NTHR) void wgrad_kernel(const WGradArgs p) {
     const bool more = rr + BK < r_end;
     if (more) load_tile();
     mma_slab_km<BF16, MT, NT, LDA, LDB>(As, Bs, wm * MT * 16, wn * NT * 16, lane, acc);
+    if (do_bias && tid < BM) {
+      float sb = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < BK; ++r) sb += (float)As[r * LDA + tid];
+      bsum += sb;
+    }
     __syncthreads();
     if (more) {
       store_tile();
@@ -582,6 +604,7 @@ __global__ __launch_bounds__(TL::NTHR) void wgrad_kernel(const WGradArgs p) {
     }
   }
 
+  if (do_bias && tid < BM && ca0 + tid < g.Co) atomicAdd(p.dbias + ca0 + tid, bsum);
   const int lr = lane & 15, lg = lane >> 4;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -675,15 +698,15 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, hi
   const int Co = a.g.Co;
   const bool bf = math == SV_MATH_BF16;
   if (Co <= 16) {
-    dim3 grid(cdiv(M, TileNarrow::BM), cdiv(Co, TileNarrow::BN), ncls);
+    dim3 grid(cdiv(M, TileNarrow::BM) * cdiv(Co, TileNarrow::BN), ncls);
     if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileNarrow>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileNarrow>), grid, dim3(256), 0, s, a);
   } else if (Co > 64 && (long long)cdiv(M, 128) * cdiv(Co, 128) * ncls >= 384) {   // 8-wave 128x128: one pass over A per 128 output columns
-    dim3 grid(cdiv(M, TileBig::BM), cdiv(Co, TileBig::BN), ncls);
+    dim3 grid(cdiv(M, TileBig::BM) * cdiv(Co, TileBig::BN), ncls);
     if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileBig>), grid, dim3(TileBig::NTHR), 0, s, a);
     else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileBig>), grid, dim3(TileBig::NTHR), 0, s, a);
   } else {
-    dim3 grid(cdiv(M, TileDefault::BM), cdiv(Co, TileDefault::BN), ncls);
+    dim3 grid(cdiv(M, TileDefault::BM) * cdiv(Co, TileDefault::BN), ncls);
     if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileDefault>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileDefault>), grid, dim3(256), 0, s, a);
   }
@@ -747,7 +770,7 @@ extern "C" size_t sv_conv_wgrad_workspace_floats(const sv_geom* g) {
 }
 
 extern "C" int sv_conv_wgrad(const float* anchor, int lda, const float* gathered, float* dw, const sv_geom* g, int cg_valid,
-                             float* workspace, int math, void* stream) {
+                             float* workspace, float* dbias, int math, void* stream) {
   SV_REQUIRE(anchor && gathered && dw && g, "wgrad: null argument");
   SV_REQUIRE(lda >= g->Co && g->ldi >= g->Ci && cg_valid > 0 && cg_valid <= g->Ci, "wgrad: bad strides (lda=%d Co=%d ldi=%d Ci=%d cg_valid=%d)",
              lda, g->Co, g->ldi, g->Ci, cg_valid);
@@ -762,6 +785,7 @@ extern "C" int sv_conv_wgrad(const float* anchor, int lda, const float* gathered
   a.anchor = anchor; a.lda = lda; a.gathered = gathered; a.g = to_geom(g); a.cg_valid = cg_valid;
   a.Mrows = (int)Mll;
   a.direct = taps == 1;
+  a.dbias = dbias;
   a.out = a.direct ? dw : workspace;
   if (!a.direct) (void)hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)g->Co * Kout, s);
   const bool narrow = g->Co <= 16;
@@ -780,7 +804,7 @@ extern "C" int sv_conv_wgrad(const float* anchor, int lda, const float* gathered
   rps = (rps + BKs - 1) / BKs * BKs;
   splits = (Mll + rps - 1) / rps;
   a.rows_per_split = (int)rps;
-  dim3 grid(cdiv(g->Co, BMw), cdiv(Kout, BNw), (unsigned)splits);
+  dim3 grid((unsigned)(cdiv(g->Co, BMw) * cdiv(Kout, BNw) * splits));
   const bool bf = math == SV_MATH_BF16;
   if (narrow) {
     if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileNarrow>), grid, dim3(256), 0, s, a);

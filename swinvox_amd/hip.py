@@ -38,7 +38,7 @@ _PROTOS = {
     "sv_conv_gather": (_I, [_P, _P, _P, C.POINTER(Geom), C.POINTER(Epilogue), _I, _P]),
     "sv_tconv_gather": (_I, [_P, _P, _P, C.POINTER(Geom), C.POINTER(Epilogue), _I, _P]),
     "sv_conv_wgrad_workspace_floats": (C.c_size_t, [C.POINTER(Geom)]),
-    "sv_conv_wgrad": (_I, [_P, _I, _P, _P, C.POINTER(Geom), _I, _P, _I, _P]),
+    "sv_conv_wgrad": (_I, [_P, _I, _P, _P, C.POINTER(Geom), _I, _P, _P, _I, _P]),
     "sv_stencil3_fwd": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "sv_stencil3_wgrad": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sv_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -111,9 +111,8 @@ class ConvBnAct:
         dy = (zeros if sp.cout_mem != sp.cout else empty)(M, sp.cout_mem, like=dz)
         st.backward(dz, lddz, z, ldz, y, sp.cout, dy, sp.cout_mem, grads[self.bn.weight], grads[self.bn.bias], self.act, self.slope,
                     dres, lddres)
-        if self.conv.bias is not None:
-            ops.colsum(dy, M, sp.cout, sp.cout_mem, grads[self.conv.bias])
-        sp.wgrad(dy, x, n, in_grid, grads[self.conv.weight], lddy=sp.cout_mem, ldx=ldi)
+        sp.wgrad(dy, x, n, in_grid, grads[self.conv.weight], lddy=sp.cout_mem, ldx=ldi,
+                 db=grads[self.conv.bias] if self.conv.bias is not None else None)
         if not need_dx:
             return None
         Min = n * in_grid[0] * in_grid[1] * in_grid[2]

@@ -202,16 +202,14 @@ class Encoder(HipModule):
                 conv = self.swin_stage_reduces[k]
                 sp = self._s_red[k]
                 rows = I * hw * hw
-                sp.wgrad(d, f, rows, (1, 1, 1), grads[conv.weight], lddy=ld)
-                ops.colsum(d, rows, 256, ld, grads[conv.bias])
+                sp.wgrad(d, f, rows, (1, 1, 1), grads[conv.weight], lddy=ld, db=grads[conv.bias])
                 df = empty(rows, sp.cin, like=dout)
                 sp.dgrad(d, rows, (1, 1, 1), sp.pack_dgrad(conv.weight), df, lddy=ld)
                 dfeats.append(df)
         else:
             f = neck[0][0]
             sp = self._s_red1
-            sp.wgrad(dcat_s, f, I * 49, (1, 1, 1), grads[self.swin_reduce.weight], lddy=512)
-            ops.colsum(dcat_s, I * 49, 256, 512, grads[self.swin_reduce.bias])
+            sp.wgrad(dcat_s, f, I * 49, (1, 1, 1), grads[self.swin_reduce.weight], lddy=512, db=grads[self.swin_reduce.bias])
             df = empty(I * 49, sp.cin, like=dout)
             sp.dgrad(dcat_s, I * 49, (1, 1, 1), sp.pack_dgrad(self.swin_reduce.weight), df, lddy=512)
             dfeats = [None] * (len(self.swin_transformer.layer_norm) - 1) + [df]
@@ -222,8 +220,7 @@ class Encoder(HipModule):
         # ---- ResNet branch
         drr = empty(I * 196, 256, like=dout)
         call("sv_avgpool2_bwd", ptr(dcat), ptr(drr), I, 14, 14, 256, 512, 0)
-        self._s_rr.wgrad(drr, res_feat, I * 196, (1, 1, 1), grads[self.resnet_reduce.weight])
-        ops.colsum(drr, I * 196, 256, 256, grads[self.resnet_reduce.bias])
+        self._s_rr.wgrad(drr, res_feat, I * 196, (1, 1, 1), grads[self.resnet_reduce.weight], db=grads[self.resnet_reduce.bias])
         d = empty(I * 196, 1024, like=dout)
         self._s_rr.dgrad(drr, I * 196, (1, 1, 1), self._s_rr.pack_dgrad(self.resnet_reduce.weight), d)
         for blk, c in reversed(c_blocks):

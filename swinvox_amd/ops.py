@@ -144,22 +144,29 @@ class ConvSpec:
         og = self.out_grid(in_grid)
         g = self._geom(n, og, in_grid, self.cout_mem, self.cin, lddy or self.cout_mem)
         e = _epilogue(lddx or self.cin_mem, **epi)
-        self._traced("sv_conv_gather" if self.transposed else "sv_tconv_gather", n, in_grid, ptr(dy), ptr(w_dgrad), ptr(dx),
+        # 1x1 / stride 1 / pad 0 (every Linear and 1x1 conv): the data-gradient is the same dense gather with the
+        # transposed weight pack -> use the plain gather kernel, no parity classes
+        dense = self.taps == 1 and self.s == (1, 1, 1) and self.p == (0, 0, 0)
+        self._traced("sv_conv_gather" if (self.transposed or dense) else "sv_tconv_gather", n, in_grid, ptr(dy), ptr(w_dgrad), ptr(dx),
                      C.byref(g), C.byref(e), _STATE["math"])
 
     # ---- weight gradient, accumulated into dw (native layout) ------------------------------------------
-    def wgrad(self, dy, x, n, in_grid, dw, *, lddy=None, ldx=None):
+    def wgrad(self, dy, x, n, in_grid, dw, *, lddy=None, ldx=None, db=None):
+        """dw += ...; for (non-transposed) conv / Linear layers db (bias gradient = column sums of dy) is folded into the
+        same kernel; transposed convs anchor on x, so their bias gradient needs the separate column-sum kernel."""
         og = self.out_grid(in_grid)
         if self.transposed:   # anchor = x (cin), gathered = dy (cout)
             g = self._geom(n, og, in_grid, self.cout_mem, self.cin, lddy or self.cout_mem)
             ws = empty(self.cin * self.taps * self.cout_mem, like=dw) if self.taps > 1 else None
             self._traced("sv_conv_wgrad", n, in_grid, ptr(x), ldx or self.cin_mem, ptr(dy), ptr(dw), C.byref(g), self.cout, ptr(ws),
-                         _STATE["math"])
+                         None, _STATE["math"])
+            if db is not None:
+                colsum(dy, n * og[0] * og[1] * og[2], self.cout, lddy or self.cout_mem, db)
         else:                 # anchor = dy (cout), gathered = x (cin)
             g = self._geom(n, in_grid, og, self.cin_mem, self.cout, ldx or self.cin_mem)
             ws = empty(self.cout * self.taps * self.cin_mem, like=dw) if self.taps > 1 else None
             self._traced("sv_conv_wgrad", n, in_grid, ptr(dy), lddy or self.cout_mem, ptr(x), ptr(dw), C.byref(g), self.cin, ptr(ws),
-                         _STATE["math"])
+                         ptr(db), _STATE["math"])
 
 
 def colsum(x, rows, cols, ld, out, accumulate=True):
@@ -178,9 +185,7 @@ def linear_dgrad(dy, rows, spec: ConvSpec, w_t, dx, **epi):
 
 
 def linear_wgrad(dy, x, rows, spec: ConvSpec, dw, db=None):
-    spec.wgrad(dy, x, rows, (1, 1, 1), dw)
-    if db is not None:
-        colsum(dy, rows, spec.cout, spec.cout_mem, db)
+    spec.wgrad(dy, x, rows, (1, 1, 1), dw, db=db)
 
 
 # ---------------------------------------------------------------------------------------------------
