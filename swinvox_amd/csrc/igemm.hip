@@ -56,7 +56,7 @@ template <int WM_, int WN_, int MT_, int NT_> struct Tile {
   static constexpr int BM = WM_ * MT_ * 16, BN = WN_ * NT_ * 16;
   static constexpr int NW = WM_ * WN_, NTHR = NW * 64;
 };
-typedef Tile<2, 2, 4, 2> TileDefault;   // 128 x 64
+typedef Tile<4, 2, 2, 2> TileDefault;   // 128 x 64, 8 waves of 32x32 (few registers per thread -> 2-3 workgroups per CU)
 typedef Tile<2, 2, 4, 4> TileWide;      // 128 x 128, 4 waves (register-heavy: measured slower, kept for reference)
 typedef Tile<2, 4, 4, 2> TileBig;       // 128 x 128, 8 waves (512 threads): halves the A re-reads of TileDefault at equal registers
 typedef Tile<4, 1, 2, 1> TileNarrow;    // 128 x 16
@@ -173,7 +173,7 @@ __device__ __forceinline__ void decode_row(int m, int c0, int c1, int c2, int& n
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------------
 template <bool BF16, bool TCONV, typename TL>
-__global__ __launch_bounds__(TL::NTHR) void igemm_kernel(const IGemmArgs p) {
+__global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kernel(const IGemmArgs p) {
   typedef typename Cfg<BF16>::T LT;
   constexpr int BK = Cfg<BF16>::BK, LD = BK + Cfg<BF16>::PAD;
   constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT;
@@ -452,7 +452,7 @@ struct WGradArgs {
 };
 
 template <bool BF16, typename TL>
-__global__ __launch_bounds__(TL::NTHR) void wgrad_kernel(const WGradArgs p) {
+__global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void wgrad_kernel(const WGradArgs p) {
   typedef typename Cfg<BF16>::T LT;
   constexpr int BK = Cfg<BF16>::BK, PAD = Cfg<BF16>::PAD;
   constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT;
@@ -707,8 +707,8 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, hi
     else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileBig>), grid, dim3(TileBig::NTHR), 0, s, a);
   } else {
     dim3 grid(cdiv(M, TileDefault::BM) * cdiv(Co, TileDefault::BN), ncls);
-    if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileDefault>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileDefault>), grid, dim3(256), 0, s, a);
+    if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileDefault>), grid, dim3(TileDefault::NTHR), 0, s, a);
+    else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileDefault>), grid, dim3(TileDefault::NTHR), 0, s, a);
   }
 }
 
