@@ -183,7 +183,8 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
   constexpr int NA = BM / RPP;
   constexpr int NB = (BN + RPP - 1) / RPP;
   constexpr int LDC = BN + 4;          // fp32 staging tile of the epilogue (aliases the operand tiles)
-  constexpr int AB_BYTES = (BM + BN) * LD * (int)sizeof(LT), C_BYTES = BM * LDC * 4;
+  constexpr int STAGE = (BM + BN) * LD;   // operand tiles are double-buffered: one barrier per K step
+  constexpr int AB_BYTES = 2 * STAGE * (int)sizeof(LT), C_BYTES = BM * LDC * 4;
   __shared__ __attribute__((aligned(16))) char smem[AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES];
   __shared__ float red[NW * BN * 2];
   LT* As = reinterpret_cast<LT*>(smem);
@@ -317,12 +318,14 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
       kcur += BK;
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    LT* A_ = As + buf * STAGE;
+    LT* B_ = Bs + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) store4(As + (rb + RPP * i) * LD + kq, ra[i]);
+    for (int i = 0; i < NA; ++i) store4(A_ + (rb + RPP * i) * LD + kq, ra[i]);
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      if (rb + RPP * i < BN) store4(Bs + (rb + RPP * i) * LD + kq, rbv[i]);
+      if (rb + RPP * i < BN) store4(B_ + (rb + RPP * i) * LD + kq, rbv[i]);
   };
 
   f32x4 acc[MT][NT];
@@ -334,16 +337,14 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
   const int nk = (K + BK - 1) / BK;
   if (nk > 0) {
     load_tile();
-    store_tile();
+    store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
       if (kt + 1 < nk) load_tile();
-      mma_slab<BF16, MT, NT>(As, Bs, wm * MT * 16, wn * NT * 16, lane, acc);
+      mma_slab<BF16, MT, NT>(As + cur * STAGE, Bs + cur * STAGE, wm * MT * 16, wn * NT * 16, lane, acc);
+      if (kt + 1 < nk) store_tile(cur ^ 1);
       __syncthreads();
-      if (kt + 1 < nk) {
-        store_tile();
-        __syncthreads();
-      }
     }
   }
 
@@ -460,8 +461,8 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void wgrad_kerne
   constexpr int NTHR = TL::NTHR;
   constexpr int A4 = BM / 4, A_RPP = NTHR / A4, A_PASS = (BK + A_RPP - 1) / A_RPP;   // float4 columns / rows per pass / passes
   constexpr int B4 = BN / 4, B_RPP = NTHR / B4, B_PASS = (BK + B_RPP - 1) / B_RPP;
-  __shared__ __attribute__((aligned(16))) LT As[BK * LDA];  // [r][ca]
-  __shared__ __attribute__((aligned(16))) LT Bs[BK * LDB];  // [r][k_out]
+  __shared__ __attribute__((aligned(16))) LT As[2 * BK * LDA];  // [stage][r][ca]     (double-buffered: one barrier / K step)
+  __shared__ __attribute__((aligned(16))) LT Bs[2 * BK * LDB];  // [stage][r][k_out]
 
   const Geom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -563,16 +564,18 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void wgrad_kerne
       }
     }
   };
-  auto store_tile = [&]() {  // natural layout: [position][channel], vector stores
+  auto store_tile = [&](int buf) {  // natural layout: [position][channel], vector stores
+    LT* A_ = As + buf * BK * LDA;
+    LT* B_ = Bs + buf * BK * LDB;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       const int rl = a_r + A_RPP * i;
-      if (rl < BK) store4(As + rl * LDA + a_c, ra[i]);
+      if (rl < BK) store4(A_ + rl * LDA + a_c, ra[i]);
     }
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
       const int rl = b_r + B_RPP * i;
-      if (rl < BK) store4(Bs + rl * LDB + b_kl, rbv[i]);
+      if (rl < BK) store4(B_ + rl * LDB + b_kl, rbv[i]);
     }
   };
 
@@ -585,23 +588,22 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void wgrad_kerne
   const bool do_bias = p.dbias != nullptr && ko0 == 0;
   float bsum = 0.f;
   load_tile();
-  store_tile();
+  store_tile(0);
   __syncthreads();
-  for (int rr = r_begin; rr < r_end; rr += BK) {
+  int cur = 0;
+  for (int rr = r_begin; rr < r_end; rr += BK, cur ^= 1) {
     const bool more = rr + BK < r_end;
+    const LT* Ac = As + cur * BK * LDA;
     if (more) load_tile();
-    mma_slab_km<BF16, MT, NT, LDA, LDB>(As, Bs, wm * MT * 16, wn * NT * 16, lane, acc);
+    mma_slab_km<BF16, MT, NT, LDA, LDB>(Ac, Bs + cur * BK * LDB, wm * MT * 16, wn * NT * 16, lane, acc);
     if (do_bias && tid < BM) {
       float sb = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < BK; ++r) sb += (float)As[r * LDA + tid];
+      for (int r = 0; r < BK; ++r) sb += (float)Ac[r * LDA + tid];
       bsum += sb;
     }
+    if (more) store_tile(cur ^ 1);
     __syncthreads();
-    if (more) {
-      store_tile();
-      __syncthreads();
-    }
   }
 
   if (do_bias && tid < BM && ca0 + tid < g.Co) atomicAdd(p.dbias + ca0 + tid, bsum);
@@ -712,7 +714,7 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, hi
   }
 }
 
-typedef Tile<2, 2, 4, 2> WTileDefault;   // 128 anchor channels x 64 (tap, gathered channel)
+typedef Tile<4, 2, 2, 2> WTileDefault;   // 128 anchor channels x 64 (tap, gathered channel), 8 waves
 typedef Tile<1, 4, 1, 2> WTileNarrow;    // 16 x 128 for <=16 anchor channels
 typedef Tile<2, 4, 4, 2> WTileWide;      // 128 x 128, 8 waves
 
@@ -813,8 +815,8 @@ extern "C" int sv_conv_wgrad(const float* anchor, int lda, const float* gathered
     if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileWide>), grid, dim3(WTileWide::NTHR), 0, s, a);
     else hipLaunchKernelGGL((wgrad_kernel<false, WTileWide>), grid, dim3(WTileWide::NTHR), 0, s, a);
   } else {
-    if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileDefault>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<false, WTileDefault>), grid, dim3(256), 0, s, a);
+    if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileDefault>), grid, dim3(WTileDefault::NTHR), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<false, WTileDefault>), grid, dim3(WTileDefault::NTHR), 0, s, a);
   }
   if (!a.direct) {
     const long long total = (long long)g->Co * cg_valid * taps;
