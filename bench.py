@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--math", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--storage", default="bf16", choices=["bf16", "f32"], help="HBM element type of the activations inside the modules")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=2)
     args = ap.parse_args()
@@ -84,6 +85,7 @@ def main():
 
     hip.load()
     S.set_math(args.math)
+    S.set_storage(args.storage if args.math == "bf16" else "f32")
     torch.manual_seed(1234 + rank)
     cfg = S.default_cfg()
     nets = [Encoder(cfg), Decoder(cfg), Merger(cfg), Refiner(cfg)]
@@ -165,7 +167,8 @@ def main():
                                    f"decoder, merger, refiner), fwd+2xBCE+bwd, train mode, B={B} samples x V={V} views of 224x224 per GPU",
                        "global_batch": world * B, "n_views": V, "images_per_gpu": B * V,
                        "parallelism": f"dp{world} (sample-sharded, RCCL gradient all-reduce)" if world > 1 else "single GPU",
-                       "math": "bf16 MFMA inputs, fp32 accumulate, fp32 activations/weights in HBM" if args.math == "bf16" else "exact fp32 MFMA"},
+                       "math": (f"bf16 MFMA inputs, fp32 accumulate, {S.get_storage()} activations / fp32 weights, statistics and gradients of weights in HBM"
+                                if args.math == "bf16" else "exact fp32 MFMA, fp32 storage")},
             "roofline": {"bound": "mfma", "kernel": "implicit-GEMM contraction engine (igemm_kernel / wgrad_kernel: all Linear/Conv/ConvTranspose fwd+dgrad+wgrad)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "algorithmic_bytes_per_launch": eng_bytes / max(eng_n, 1),

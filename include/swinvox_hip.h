@@ -9,7 +9,8 @@
  * these through ctypes and mirrors the reference's nn.Module surface.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer to fp32 data unless said otherwise; the library never allocates,
+ *   - every pointer is a DEVICE pointer; typed pointers are fp32 (or as declared), void* activation pointers hold the
+ *     element type named by the call's `act_dtype` (SV_F32 / SV_BF16, see below); the library never allocates,
  *     frees or retains memory (all buffers, including workspaces, are owned by the caller);
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only enqueues work;
  *   - return value: 0 on success, <0 on error (SV_ERR_*); sv_last_error() returns a message for the
@@ -33,7 +34,12 @@ extern "C" {
 
 enum { SV_ACT_NONE = 0, SV_ACT_RELU = 1, SV_ACT_GELU = 2, SV_ACT_LRELU = 3 };
 #define SV_BN_SLOTS 16 /* BatchNorm statistic accumulators are [SV_BN_SLOTS][2*C] doubles (contention spreading) */
-enum { SV_MATH_F32 = 0, SV_MATH_BF16 = 1 }; /* MFMA input type of the contraction kernels; I/O and accumulation stay fp32 */
+enum { SV_MATH_F32 = 0, SV_MATH_BF16 = 1 }; /* MFMA input type of the contraction kernels; accumulation stays fp32 */
+/* Storage type of ACTIVATIONS (and activation gradients) in HBM.  Entry points with an `act_dtype` argument take their
+ * activation tensors as void*: every such tensor of one call has this element type.  Parameters, parameter gradients,
+ * statistics (mean/rstd/scale/shift/sums), workspaces and drop-path scales are always fp32 (or double where noted).
+ * Arithmetic is fp32 in both cases; SV_BF16 halves the HBM traffic of the path (values are rounded to nearest-even on store). */
+enum { SV_F32 = 0, SV_BF16 = 1 };
 
 const char* sv_last_error(void);
 int sv_version(void);
@@ -58,50 +64,54 @@ typedef struct sv_geom {
 
 typedef struct sv_epilogue {
   const float* bias;     /* [Co] or NULL */
-  const float* residual; /* same positions as the output, row stride ldr, or NULL:  out = residual + scale*val */
+  const void* residual;  /* ACTIVATION (act_dtype): same positions as the output, row stride ldr, or NULL:  out = residual + scale*val */
   int ldr;
   const float* row_scale; /* optional per-image scale of val before the residual add (drop-path), index = row / rows_per_scale */
   int rows_per_scale;
-  float* pre_act;        /* optional: receives val (after bias, before activation), same layout as out */
+  void* pre_act;         /* ACTIVATION (act_dtype), optional: receives val (after bias, before activation), same layout as out */
   double* stats;         /* optional [SV_BN_SLOTS][2*Co] DOUBLES: atomically accumulates sum and sum-of-squares of the stored output per channel */
   int act;               /* SV_ACT_* applied to val (after bias) */
   float slope;           /* LeakyReLU slope */
-  const float* act_grad_src; /* optional: val *= act'(act_grad_src[pos]) (backward through an activation), layout of out */
+  const void* act_grad_src; /* ACTIVATION (act_dtype), optional: val *= act'(act_grad_src[pos]) (backward through an activation), layout of out */
   int act_grad_kind;     /* SV_ACT_* of that activation */
   int ldc;               /* output row stride (elements) */
   int col_off;           /* first output column */
 } sv_epilogue;
 
 /* gather form:  out[o, co] = sum_{tap,ci} in[o*s - p + tap, ci] * w[co, tap, ci]      (conv forward; tconv data-grad; Linear) */
-int sv_conv_gather(const float* in, const float* w_packed, float* out, const sv_geom* g, const sv_epilogue* e,
-                   int math, void* stream);
+int sv_conv_gather(const void* in, const float* w_packed, void* out, const sv_geom* g, const sv_epilogue* e,
+                   int math, int act_dtype, void* stream);
 /* scatter-as-gather form: out[o, co] = sum_{tap,ci : (o+p-tap)%s==0} in[(o+p-tap)/s, ci] * w[co, tap, ci]
  * (transposed-conv forward; strided-conv data-grad), decomposed per output parity class            */
-int sv_tconv_gather(const float* in, const float* w_packed, float* out, const sv_geom* g, const sv_epilogue* e,
-                    int math, void* stream);
+int sv_tconv_gather(const void* in, const float* w_packed, void* out, const sv_geom* g, const sv_epilogue* e,
+                    int math, int act_dtype, void* stream);
 /* weight gradient: dw[ca, cg, tap] += sum_r anchor[r, ca] * gathered[r*s - p + tap, cg]   (fp32 atomics; dw pre-zeroed
  * or holding a running sum).  g->Do.. = anchor grid, g->Di.. = gathered grid, g->Co = anchor channels (row stride lda),
  * g->Ci = gathered channels (stride g->ldi); only cg < cg_valid is written; dw index = (ca*cg_valid + cg)*taps + tap.
  * When the kernel has more than one tap the partial sums are gathered in `workspace`
  * (sv_conv_wgrad_workspace_floats(g) floats, caller-owned, contents destroyed) and folded into dw by a second kernel. */
 size_t sv_conv_wgrad_workspace_floats(const sv_geom* g);
-int sv_conv_wgrad(const float* anchor, int lda, const float* gathered, float* dw, const sv_geom* g, int cg_valid,
-                  float* workspace, float* dbias /* optional: dbias[ca] += sum_r anchor[r, ca] */, int math, void* stream);
+int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, float* dw, const sv_geom* g, int cg_valid,
+                  float* workspace, float* dbias /* optional: dbias[ca] += sum_r anchor[r, ca] */, int math, int act_dtype,
+                  void* stream);
 /* LDS-halo MFMA stencils for 3x3x3 / stride 1 / pad 1 convolutions with <= 16 output channels per tile (merger.py:20-54),
- * bf16 operands.  x: channels-last positions with row stride ldx, cin_load (multiple of 4) floats read per position,
+ * bf16 operands.  x: channels-last positions with row stride ldx, cin_load (multiple of 4) elements read per position,
  * zero-extended to 16*groups channels; w_bf16: [16*ntiles16][27][16*groups] bf16 (forward: rows = output channels;
  * data-gradient: rows = input channels, taps flipped).  Writes out[pos*ldc + col_off + n] for n < cout
  * (= residual + value when residual != NULL); optional per-channel statistics as in sv_epilogue.stats. */
-int sv_stencil3_fwd(const float* x, int ldx, int cin_load, int groups, const void* w_bf16, int ntiles16,
-                    const float* bias, float* out, int ldc, int col_off, int cout, const float* residual, int ldr,
-                    double* stats, int I, int D, int H, int W, void* stream);
+int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups, const void* w_bf16, int ntiles16,
+                    const float* bias, void* out, int ldc, int col_off, int cout, const void* residual, int ldr,
+                    double* stats, int I, int D, int H, int W, int act_dtype, void* stream);
 /* dw[co][ci][27] += sum_vox dy[vox][co] * x[vox + tap][c]; memory channel c maps to ci = (c / c_stride)*c_valid + c % c_stride */
-int sv_stencil3_wgrad(const float* x, int ldx, int cin_load, int groups, const float* dy, int lddy, int cout_load,
-                      float* dw, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W, void* stream);
-/* dst[a][t][b] (b padded with zeros to bpad) from src[a][b][t]  (swap=0), or dst[b][t][a..apad] (swap=1) */
+int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int groups, const void* dy, int lddy, int cout_load,
+                      float* dw, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W, int act_dtype,
+                      void* stream);
+/* dst[a][t][b] (b padded with zeros to bpad) from src[a][b][t]  (swap=0), or dst[b][t][a..apad] (swap=1)   (weights: fp32) */
 int sv_pack_weight(const float* src, float* dst, int A, int B, int T, int swap, int pad_to, void* stream);
 /* per-column sum over rows: out[c] (+)= sum_r x[r*ld + c]  (bias gradients) */
-int sv_colsum(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* stream);
+int sv_colsum(const void* x, int rows, int cols, int ld, float* out, int accumulate, int act_dtype, void* stream);
+/* element-wise storage conversion (module boundaries: nn.Module inputs / outputs are fp32) */
+int sv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Normalisation.  Token LayerNorm = timm norm1/norm2/patch_embed.norm/downsample.norm (eps 1e-5); with
@@ -110,71 +120,77 @@ int sv_colsum(const float* x, int rows, int cols, int ld, float* out, int accumu
  * models/swin_transformer.py:64-69,82-89 on NHWC data with the affine pre-transposed to [HW,C].
  * BatchNorm = nn.BatchNorm2d/3d of models/encoder.py, cross_view_attention.py:56, decoder.py, merger.py,
  * refiner.py on channels-last [M,C] (biased batch variance, unbiased running update, eps 1e-5).
+ * x / y / dx / dy / z / dz / residual / dres are activations (act_dtype); everything else is fp32 (double where declared).
  * ---------------------------------------------------------------------------------------------- */
-int sv_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                     long long rows, int C, float eps, int merge_H, int merge_W, void* stream);
-int sv_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                     float* dx, float* dgamma, float* dbeta, long long rows, int C, int merge_H, int merge_W,
-                     int accumulate_dx, void* stream);
+int sv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                     long long rows, int C, float eps, int merge_H, int merge_W, int act_dtype, void* stream);
+int sv_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                     void* dx, float* dgamma, float* dbeta, long long rows, int C, int merge_H, int merge_W,
+                     int accumulate_dx, int act_dtype, void* stream);
 size_t sv_ln_image_workspace_floats(int I, int L);
-int sv_ln_image_fwd(const float* x, const float* w, const float* b, float* y, float* meanrstd, float* workspace,
-                    int I, int L, float eps, float drop_p, uint32_t seed, void* stream);
-int sv_ln_image_bwd(const float* dy, const float* x, const float* w, const float* meanrstd, float* dx, float* dw,
-                    float* db, double* sums_ws /* [2*I] doubles */, int I, int L, float drop_p, uint32_t seed, void* stream);
-int sv_bn_stats(const float* x, long long M, int C, int ld, double* sums, void* stream);   /* sums: [SV_BN_SLOTS][2*C] doubles (slot 0 is used) */
+int sv_ln_image_fwd(const void* x, const float* w, const float* b, void* y, float* meanrstd, float* workspace,
+                    int I, int L, float eps, float drop_p, uint32_t seed, int act_dtype, void* stream);
+int sv_ln_image_bwd(const void* dy, const void* x, const float* w, const float* meanrstd, void* dx, float* dw,
+                    float* db, double* sums_ws /* [2*I] doubles */, int I, int L, float drop_p, uint32_t seed, int act_dtype,
+                    void* stream);
+int sv_bn_stats(const void* x, long long M, int C, int ld, double* sums, int act_dtype, void* stream);   /* sums: [SV_BN_SLOTS][2*C] doubles (slot 0 is used) */
 int sv_bn_finalize(const double* sums, long long count, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float momentum, float eps, int training, float* scale, float* shift,
                    float* save_mean, float* save_rstd, int C, void* stream);
-int sv_scale_shift_act(const float* x, int ldx, const float* scale, const float* shift, const float* residual, int ldr,
-                       float* y, int ldy, long long M, int C, int act, float slope, void* stream);
-int sv_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const float* x, int ldx, const float* gamma,
+int sv_scale_shift_act(const void* x, int ldx, const float* scale, const float* shift, const void* residual, int ldr,
+                       void* y, int ldy, long long M, int C, int act, float slope, int act_dtype, void* stream);
+int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const void* x, int ldx, const float* gamma,
               const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
-              float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws /* [2*C] doubles */, void* stream);
+              void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws /* [2*C] doubles */,
+              int act_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention cores.  Window attention = timm WindowAttention + SwinTransformerBlock roll/partition/mask
  * (call site models/swin_transformer.py:78): qkv [I*H*W, 3C] rows in natural (h,w) order, columns
- * [q|k|v][head][32]; table [169, heads]; out [I*H*W, C].  Cross-view attention = models/
+ * [q|k|v][head][32]; table [169, heads] (fp32 parameter); out [I*H*W, C].  Cross-view attention = models/
  * cross_view_attention.py:78-105: qkv [B*V*P, 3R] channels-last rows (view image, position), scores over
- * the V views of one sample scaled by 1/sqrt(head_dim*V).
+ * the V views of one sample scaled by 1/sqrt(head_dim*V).  qkv / out / dout / dqkv are activations (act_dtype;
+ * SV_BF16 requires math = SV_MATH_BF16); softmax statistics and the bias-table gradient stay fp32.
  * ---------------------------------------------------------------------------------------------- */
-int sv_window_attention_fwd(const float* qkv, const float* table, float* out, int I, int H, int W, int C, int heads,
-                            int shift, int math, void* stream);
-int sv_window_attention_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable,
-                            int I, int H, int W, int C, int heads, int shift, int math, void* stream);
-int sv_cross_view_attention_fwd(const float* qkv, float* out, int B, int V, int P, int R, int heads, void* stream);
-int sv_cross_view_attention_bwd(const float* qkv, const float* dout, float* dqkv, int B, int V, int P, int R, int heads,
-                                void* stream);
+int sv_window_attention_fwd(const void* qkv, const float* table, void* out, int I, int H, int W, int C, int heads,
+                            int shift, int math, int act_dtype, void* stream);
+int sv_window_attention_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable,
+                            int I, int H, int W, int C, int heads, int shift, int math, int act_dtype, void* stream);
+int sv_cross_view_attention_fwd(const void* qkv, void* out, int B, int V, int P, int R, int heads, int act_dtype, void* stream);
+int sv_cross_view_attention_bwd(const void* qkv, const void* dout, void* dqkv, int B, int V, int P, int R, int heads,
+                                int act_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Layout / pooling / tail kernels (reference sites in the comments of csrc/elementwise.hip)
+ * Layout / pooling / tail kernels (reference sites in the comments of csrc/elementwise.hip).  void* tensors are
+ * activations (act_dtype); weights, their gradients, pooling indices and drop-path scales keep their declared types.
  * ---------------------------------------------------------------------------------------------- */
-int sv_transpose(const float* src, float* dst, int batch, int R, int C, int lds, int ldd, long long src_bstride,
-                 long long dst_bstride, void* stream);                       /* dst[b][c][r] = src[b][r][c] */
-int sv_add_n(const float* a, const float* b, const float* c, const float* d, float* out, long long M, int C, int ldo, void* stream);
-int sv_axpby(const float* a, const float* b, float* out, float alpha, float beta, long long n, void* stream);
-int sv_relu_bwd(const float* dy, const float* y, float* out, long long n, void* stream);               /* refiner.py:51 (ReLU after layer5) */
-int sv_maxpool2d_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);   /* 3x3 s2 p1, encoder.py:23 (resnet maxpool) */
-int sv_maxpool2d_bwd(const float* dy, const uint8_t* idx, float* dx_zeroed, int N, int H, int W, int C, void* stream);
-int sv_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int ldy, int col_off, void* stream); /* encoder.py:123 */
-int sv_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, int ldy, int col_off, void* stream);
-int sv_decoder_seed_fwd(const float* feat, float* out, int I, int C, void* stream);                      /* decoder.py:59-67 */
-int sv_decoder_seed_bwd(const float* dout, float* dfeat, int I, int C, void* stream);
-int sv_maxpool3d_fwd(const float* x, float* y, uint8_t* idx, int N, int D, int H, int W, int C, void* stream); /* refiner.py:25,31,37 */
-int sv_maxpool3d_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int D, int H, int W, int C, void* stream);
-int sv_dropout(const float* x, float* y, long long n, float p, uint32_t seed, void* stream);            /* cross_view_attention.py:57,131 */
+int sv_transpose(const void* src, void* dst, int batch, int R, int C, int lds, int ldd, long long src_bstride,
+                 long long dst_bstride, int act_dtype, void* stream);                       /* dst[b][c][r] = src[b][r][c] */
+int sv_add_n(const void* a, const void* b, const void* c, const void* d, void* out, long long M, int C, int ldo, int act_dtype, void* stream);
+int sv_axpby(const void* a, const void* b, void* out, float alpha, float beta, long long n, int act_dtype, void* stream);
+int sv_relu_bwd(const void* dy, const void* y, void* out, long long n, int act_dtype, void* stream);               /* refiner.py:51 (ReLU after layer5) */
+int sv_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int act_dtype, void* stream);   /* 3x3 s2 p1, encoder.py:23 (resnet maxpool) */
+int sv_maxpool2d_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int act_dtype, void* stream);   /* writes every dx element (no pre-zeroing) */
+int sv_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int ldy, int col_off, int act_dtype, void* stream); /* encoder.py:123 */
+int sv_avgpool2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int ldy, int col_off, int act_dtype, void* stream);
+int sv_decoder_seed_fwd(const void* feat, void* out, int I, int C, int act_dtype, void* stream);                      /* decoder.py:59-67 */
+int sv_decoder_seed_bwd(const void* dout, void* dfeat, int I, int C, int act_dtype, void* stream);
+int sv_maxpool3d_fwd(const void* x, void* y, uint8_t* idx, int N, int D, int H, int W, int C, int act_dtype, void* stream); /* refiner.py:25,31,37 */
+int sv_maxpool3d_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int D, int H, int W, int C, int act_dtype, void* stream);
+int sv_dropout(const void* x, void* y, long long n, float p, uint32_t seed, int act_dtype, void* stream);            /* cross_view_attention.py:57,131 */
 int sv_droppath_scale(float* scale, int I, float p, uint32_t seed, void* stream);                        /* timm DropPath */
-int sv_rowscale(const float* x, const float* scale, float* y, long long rows, int C, int rows_per_scale, void* stream);
-int sv_dwconv2x2_fwd(const float* x, const float* w, const float* b, float* y, int I, int C, void* stream); /* cross_view_attention.py:26-32,68 */
-int sv_dwconv2x2_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int I, int C, void* stream);
-int sv_upsample3to7_add_fwd(const float* small, const float* x, int ldx, float* y, int I, int C, void* stream); /* cross_view_attention.py:110-120 */
-int sv_upsample3to7_bwd(const float* dy, float* dsmall, int I, int C, void* stream);
-int sv_decoder_head_fwd(const float* x8, const float* w, const float* bias, float* raw12, float* vol, long long M, void* stream); /* decoder.py:83-94 */
-int sv_decoder_head_bwd(const float* draw12, const float* dvol, const float* x8, const float* w, float* dx8, float* dw, float* dbias,
-                        long long M, void* stream);
-int sv_merge_views_fwd(const float* wlogit, const float* vol, float* out, int B, int V, int S, void* stream);  /* merger.py:91-104 */
-int sv_merge_views_bwd(const float* wlogit, const float* vol, const float* out, const float* dout, float* dwlogit, float* dvol,
-                       int B, int V, int S, void* stream);
+int sv_rowscale(const void* x, const float* scale, void* y, long long rows, int C, int rows_per_scale, int act_dtype, void* stream);
+int sv_dwconv2x2_fwd(const void* x, const float* w, const float* b, void* y, int I, int C, int act_dtype, void* stream); /* cross_view_attention.py:26-32,68 */
+int sv_dwconv2x2_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int I, int C, int act_dtype, void* stream);
+int sv_upsample3to7_add_fwd(const void* small, const void* x, int ldx, void* y, int I, int C, int act_dtype, void* stream); /* cross_view_attention.py:110-120 */
+int sv_upsample3to7_bwd(const void* dy, void* dsmall, int I, int C, int act_dtype, void* stream);
+int sv_decoder_head_fwd(const void* x8, const float* w, const float* bias, void* raw12, void* vol, long long M, int act_dtype, void* stream); /* decoder.py:83-94 */
+int sv_decoder_head_bwd(const void* draw12, const void* dvol, const void* x8, const float* w, void* dx8, float* dw, float* dbias,
+                        long long M, int act_dtype, void* stream);
+int sv_merge_views_fwd(const void* wlogit, const void* vol, void* out, int B, int V, int S, int act_dtype, void* stream);  /* merger.py:91-104 */
+int sv_merge_views_bwd(const void* wlogit, const void* vol, const void* out, const void* dout, void* dwlogit, void* dvol,
+                       int B, int V, int S, int act_dtype, void* stream);
+/* harness-side kernels on fp32 module outputs */
 int sv_mean_views(const float* vol, float* out, int B, int V, int S, void* stream);                      /* core/train.py:246 */
 int sv_bce_logits(const float* x, const float* t, long long n, float* loss_accum, float* dx, const float* gscale_dev, void* stream); /* core/train.py:165,249,255 */
 int sv_iou_counts(const float* logits, const float* gt, const float* thresholds_dev, int nth, int B, int S, float* counts, void* stream); /* core/test.py:141-153 */

@@ -16,11 +16,13 @@ constexpr int LDP_F = 68;    // fp32 row stride of the P tile
 constexpr int LDQ_H = 40;    // bf16 row stride of q/k tiles
 constexpr int LDP_H = 72;    // bf16 row stride of P and V^T tiles
 
-struct WinArgs {
-  const float* qkv; const float* table; float* out;   // fwd
-  const float* dout; float* dqkv; float* dtable;      // bwd
+template <typename AT>
+struct WinArgsT {   // AT = storage element of the activations (qkv, out and their gradients)
+  const AT* qkv; const float* table; AT* out;   // fwd
+  const AT* dout; AT* dqkv; float* dtable;      // bwd
   int I, H, W, C, heads, shift; float scale; int ntasks; int tasks_per_wave;
 };
+typedef WinArgsT<float> WinArgs;
 
 struct TokMap {  // window -> token rows of the un-shifted [I,H,W] map
   int img, wy, wx, H, W, shift;
@@ -91,21 +93,22 @@ __device__ __forceinline__ void bias_mask_softmax(f32x4 (&s)[4][4], const float*
 }
 
 // load one [49(64) x 32] head slice of q, k or v (or dO) into an fp32 LDS tile, rows >= 49 zeroed
-__device__ __forceinline__ void load_tile_f32(float* dst, const float* src, int ld, int col, const TokMap& tm, int lane, float mul) {
+template <typename AT>
+__device__ __forceinline__ void load_tile_f32(float* dst, const AT* src, int ld, int col, const TokMap& tm, int lane, float mul) {
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int r = (lane >> 3) + 8 * it, ch = (lane & 7) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < WT) {
-      v = *reinterpret_cast<const float4*>(src + (size_t)tm.row(r) * ld + col + ch);
+      v = ld4f(src + (size_t)tm.row(r) * ld + col + ch);
       v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
     }
     *reinterpret_cast<float4*>(dst + r * LDQ_F + ch) = v;
   }
 }
 
-template <bool BF16>
-__global__ __launch_bounds__(256) void win_attn_fwd_kernel(const WinArgs p) {
+template <bool BF16, typename AT>
+__global__ __launch_bounds__(256) void win_attn_fwd_kernel(const WinArgsT<AT> p) {
   constexpr int WAVE_BYTES = BF16 ? (2 * 64 * LDQ_H + HD * LDP_H) * 2 + 176 * 4 : 3 * 64 * LDQ_F * 4 + 176 * 4;
   __shared__ __attribute__((aligned(16))) char smem[4 * WAVE_BYTES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -182,10 +185,10 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const WinArgs p) {
       const int r = (lane >> 3) + 8 * it, ch = (lane & 7) * 4;
       float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;
       if (r < WT) {
-        const float* src = p.qkv + (size_t)tm.row(r) * ld + colq + ch;
-        q4 = *reinterpret_cast<const float4*>(src);
-        k4 = *reinterpret_cast<const float4*>(src + p.C);
-        v4 = *reinterpret_cast<const float4*>(src + 2 * p.C);
+        const AT* src = p.qkv + (size_t)tm.row(r) * ld + colq + ch;
+        q4 = ld4f(src);
+        k4 = ld4f(src + p.C);
+        v4 = ld4f(src + 2 * p.C);
       }
       bf16x4 qb, kb;
       qb[0] = (__bf16)(q4.x * p.scale); qb[1] = (__bf16)(q4.y * p.scale); qb[2] = (__bf16)(q4.z * p.scale); qb[3] = (__bf16)(q4.w * p.scale);
@@ -237,9 +240,9 @@ __global__ __launch_bounds__(256) void win_attn_fwd_kernel(const WinArgs p) {
       for (int j = 0; j < 4; ++j) {
         const int q = mt * 16 + lg * 4 + j;
         if (q < WT) {
-          float* dst = p.out + (size_t)tm.row(q) * p.C + colq;
-          dst[lr] = o[mt][0][j];
-          dst[16 + lr] = o[mt][1][j];
+          AT* dst = p.out + (size_t)tm.row(q) * p.C + colq;
+          stf(dst + lr, o[mt][0][j]);
+          stf(dst + 16 + lr, o[mt][1][j]);
         }
       }
   }
@@ -447,19 +450,21 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int row0, 
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__device__ __forceinline__ void load_tile_bf16(__bf16* dst, const float* src, int ld, int col, const TokMap& tm, int lane, float mul) {
+template <typename AT>
+__device__ __forceinline__ void load_tile_bf16(__bf16* dst, const AT* src, int ld, int col, const TokMap& tm, int lane, float mul) {
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int r = (lane >> 3) + 8 * it, ch = (lane & 7) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < WT) v = *reinterpret_cast<const float4*>(src + (size_t)tm.row(r) * ld + col + ch);
+    if (r < WT) v = ld4f(src + (size_t)tm.row(r) * ld + col + ch);
     bf16x4 b;
     b[0] = (__bf16)(v.x * mul); b[1] = (__bf16)(v.y * mul); b[2] = (__bf16)(v.z * mul); b[3] = (__bf16)(v.w * mul);
     *reinterpret_cast<bf16x4*>(dst + r * LDQ_H + ch) = b;
   }
 }
 
-__global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(const WinArgs p) {
+template <typename AT>
+__global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(const WinArgsT<AT> p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * BWD16_WAVE_BYTES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
@@ -570,8 +575,8 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(const WinArgs p)
           for (int j = 0; j < 4; ++j) {
             const int key = mt * 16 + lg * 4 + j;
             if (key < WT) {
-              float* dst = p.dqkv + (size_t)tm.row(key) * ld + 2 * p.C + colq;
-              dst[lr] = acc[mt][0][j]; dst[16 + lr] = acc[mt][1][j];
+              AT* dst = p.dqkv + (size_t)tm.row(key) * ld + 2 * p.C + colq;
+              stf(dst + lr, acc[mt][0][j]); stf(dst + 16 + lr, acc[mt][1][j]);
             }
           }
       }
@@ -620,9 +625,9 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(const WinArgs p)
           for (int j = 0; j < 4; ++j) {
             const int t = mt * 16 + lg * 4 + j;
             if (t < WT) {
-              float* dst = p.dqkv + (size_t)tm.row(t) * ld + colq;
-              dst[lr] = aq[mt][0][j] * p.scale; dst[16 + lr] = aq[mt][1][j] * p.scale;
-              dst[p.C + lr] = ak[mt][0][j]; dst[p.C + 16 + lr] = ak[mt][1][j];
+              AT* dst = p.dqkv + (size_t)tm.row(t) * ld + colq;
+              stf(dst + lr, aq[mt][0][j] * p.scale); stf(dst + 16 + lr, aq[mt][1][j] * p.scale);
+              stf(dst + p.C + lr, ak[mt][0][j]); stf(dst + p.C + 16 + lr, ak[mt][1][j]);
             }
           }
       }
@@ -641,23 +646,26 @@ __global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(const WinArgs p)
 // ------------------------------------------------------------------------------------------------
 constexpr int CVA_MAXV = 32, CVA_MAXF = 288;
 
-struct CvaArgs { const float* qkv; float* out; const float* dout; float* dqkv; int B, V, P, R, heads, hd; float scale; };
+template <typename AT>
+struct CvaArgsT { const AT* qkv; AT* out; const AT* dout; AT* dqkv; int B, V, P, R, heads, hd; float scale; };
 
-__device__ __forceinline__ size_t cva_off(const CvaArgs& p, int b, int v, int f, int head, int which, int ld) {
+template <typename AT>
+__device__ __forceinline__ size_t cva_off(const CvaArgsT<AT>& p, int b, int v, int f, int head, int which, int ld) {
   const int pos = f / p.hd, c = f - pos * p.hd;
   return ((size_t)(b * p.V + v) * p.P + pos) * ld + which * p.R + head * p.hd + c;
 }
 
-__global__ __launch_bounds__(256) void cva_attn_fwd_kernel(const CvaArgs p) {
+template <typename AT>
+__global__ __launch_bounds__(256) void cva_attn_fwd_kernel(const CvaArgsT<AT> p) {
   __shared__ float q[CVA_MAXV * CVA_MAXF], k[CVA_MAXV * CVA_MAXF], v[CVA_MAXV * CVA_MAXF];
   __shared__ float a[CVA_MAXV * CVA_MAXV];
   const int b = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
   const int F = p.P * p.hd, V = p.V;
   for (int i = threadIdx.x; i < V * F; i += 256) {
     const int vi = i / F, f = i - vi * F;
-    q[i] = p.qkv[cva_off(p, b, vi, f, head, 0, 3 * p.R)];
-    k[i] = p.qkv[cva_off(p, b, vi, f, head, 1, 3 * p.R)];
-    v[i] = p.qkv[cva_off(p, b, vi, f, head, 2, 3 * p.R)];
+    q[i] = ldf(p.qkv + cva_off(p, b, vi, f, head, 0, 3 * p.R));
+    k[i] = ldf(p.qkv + cva_off(p, b, vi, f, head, 1, 3 * p.R));
+    v[i] = ldf(p.qkv + cva_off(p, b, vi, f, head, 2, 3 * p.R));
   }
   __syncthreads();
   for (int ij = threadIdx.x; ij < V * V; ij += 256) {
@@ -680,21 +688,22 @@ __global__ __launch_bounds__(256) void cva_attn_fwd_kernel(const CvaArgs p) {
     const int vi = i / F, f = i - vi * F;
     float o = 0.f;
     for (int j = 0; j < V; ++j) o += a[vi * V + j] * v[j * F + f];
-    p.out[cva_off(p, b, vi, f, head, 0, p.R)] = o;
+    stf(p.out + cva_off(p, b, vi, f, head, 0, p.R), o);
   }
 }
 
-__global__ __launch_bounds__(256) void cva_attn_bwd_kernel(const CvaArgs p) {
+template <typename AT>
+__global__ __launch_bounds__(256) void cva_attn_bwd_kernel(const CvaArgsT<AT> p) {
   __shared__ float q[CVA_MAXV * CVA_MAXF], k[CVA_MAXV * CVA_MAXF], v[CVA_MAXV * CVA_MAXF], d[CVA_MAXV * CVA_MAXF];
   __shared__ float a[CVA_MAXV * CVA_MAXV], ds[CVA_MAXV * CVA_MAXV];
   const int b = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
   const int F = p.P * p.hd, V = p.V;
   for (int i = threadIdx.x; i < V * F; i += 256) {
     const int vi = i / F, f = i - vi * F;
-    q[i] = p.qkv[cva_off(p, b, vi, f, head, 0, 3 * p.R)];
-    k[i] = p.qkv[cva_off(p, b, vi, f, head, 1, 3 * p.R)];
-    v[i] = p.qkv[cva_off(p, b, vi, f, head, 2, 3 * p.R)];
-    d[i] = p.dout[cva_off(p, b, vi, f, head, 0, p.R)];
+    q[i] = ldf(p.qkv + cva_off(p, b, vi, f, head, 0, 3 * p.R));
+    k[i] = ldf(p.qkv + cva_off(p, b, vi, f, head, 1, 3 * p.R));
+    v[i] = ldf(p.qkv + cva_off(p, b, vi, f, head, 2, 3 * p.R));
+    d[i] = ldf(p.dout + cva_off(p, b, vi, f, head, 0, p.R));
   }
   __syncthreads();
   for (int ij = threadIdx.x; ij < V * V; ij += 256) {
@@ -723,9 +732,9 @@ __global__ __launch_bounds__(256) void cva_attn_bwd_kernel(const CvaArgs p) {
       dk += ds[j * V + vi] * q[j * F + f];
       dv += a[j * V + vi] * d[j * F + f];
     }
-    p.dqkv[cva_off(p, b, vi, f, head, 0, 3 * p.R)] = dq;
-    p.dqkv[cva_off(p, b, vi, f, head, 1, 3 * p.R)] = dk;
-    p.dqkv[cva_off(p, b, vi, f, head, 2, 3 * p.R)] = dv;
+    stf(p.dqkv + cva_off(p, b, vi, f, head, 0, 3 * p.R), dq);
+    stf(p.dqkv + cva_off(p, b, vi, f, head, 1, 3 * p.R), dk);
+    stf(p.dqkv + cva_off(p, b, vi, f, head, 2, 3 * p.R), dv);
   }
 }
 
@@ -733,46 +742,66 @@ __global__ __launch_bounds__(256) void cva_attn_bwd_kernel(const CvaArgs p) {
 
 using namespace sv;
 
-static int win_check(const float* qkv, const float* table, int I, int H, int W, int C, int heads, int shift) {
+static int win_check(const void* qkv, const float* table, int I, int H, int W, int C, int heads, int shift, int math, int act_dtype) {
   SV_REQUIRE(qkv && table && I > 0, "window_attention: null/empty argument");
   SV_REQUIRE(H % 7 == 0 && W % 7 == 0 && H >= 7 && W >= 7, "window_attention: map %dx%d is not a multiple of the 7x7 window", H, W);
   SV_REQUIRE(C == heads * HD, "window_attention: C (%d) must equal heads (%d) * 32", C, heads);
   SV_REQUIRE(shift >= 0 && shift < 7 && (shift == 0 || (H > 7 && W > 7)), "window_attention: bad shift %d for map %dx%d", shift, H, W);
   SV_REQUIRE(((uintptr_t)qkv & 15) == 0, "window_attention: qkv must be 16-byte aligned");
+  SV_REQUIRE_ACT(act_dtype);
+  SV_REQUIRE(act_dtype == SV_F32 || math == SV_MATH_BF16, "window_attention: bf16 activations require SV_MATH_BF16");
   return SV_OK;
 }
 
-extern "C" int sv_window_attention_fwd(const float* qkv, const float* table, float* out, int I, int H, int W, int C, int heads,
-                                       int shift, int math, void* stream) {
-  if (int rc = win_check(qkv, table, I, H, W, C, heads, shift)) return rc;
-  SV_REQUIRE(out, "window_attention_fwd: null out");
-  WinArgs a{};
-  a.qkv = qkv; a.table = table; a.out = out; a.I = I; a.H = H; a.W = W; a.C = C; a.heads = heads; a.shift = shift;
-  a.scale = 1.0f / sqrtf((float)HD);
-  a.ntasks = I * (H / 7) * (W / 7);
-  dim3 grid(cdiv(a.ntasks, 4), heads);
-  if (math == SV_MATH_BF16) hipLaunchKernelGGL((win_attn_fwd_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((win_attn_fwd_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
-  return check_launch("sv_window_attention_fwd");
-}
-
-extern "C" int sv_window_attention_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable,
-                                       int I, int H, int W, int C, int heads, int shift, int math, void* stream) {
-  if (int rc = win_check(qkv, table, I, H, W, C, heads, shift)) return rc;
-  SV_REQUIRE(dout && dqkv && dtable && ((uintptr_t)dout & 15) == 0, "window_attention_bwd: null/unaligned argument");
-  WinArgs a{};
-  a.qkv = qkv; a.table = table; a.dout = dout; a.dqkv = dqkv; a.dtable = dtable;
+template <typename AT>
+static WinArgsT<AT> win_args(const void* qkv, const float* table, void* out, const void* dout, void* dqkv, float* dtable, int I, int H, int W,
+                             int C, int heads, int shift) {
+  WinArgsT<AT> a{};
+  a.qkv = static_cast<const AT*>(qkv); a.table = table; a.out = static_cast<AT*>(out);
+  a.dout = static_cast<const AT*>(dout); a.dqkv = static_cast<AT*>(dqkv); a.dtable = dtable;
   a.I = I; a.H = H; a.W = W; a.C = C; a.heads = heads; a.shift = shift;
   a.scale = 1.0f / sqrtf((float)HD);
   a.ntasks = I * (H / 7) * (W / 7);
+  return a;
+}
+
+extern "C" int sv_window_attention_fwd(const void* qkv, const float* table, void* out, int I, int H, int W, int C, int heads,
+                                       int shift, int math, int act_dtype, void* stream) {
+  if (int rc = win_check(qkv, table, I, H, W, C, heads, shift, math, act_dtype)) return rc;
+  SV_REQUIRE(out, "window_attention_fwd: null out");
+  const int ntasks = I * (H / 7) * (W / 7);
+  dim3 grid(cdiv(ntasks, 4), heads);
+  hipStream_t s = (hipStream_t)stream;
+  if (act_dtype == SV_BF16)
+    hipLaunchKernelGGL((win_attn_fwd_kernel<true, __bf16>), grid, dim3(256), 0, s, win_args<__bf16>(qkv, table, out, nullptr, nullptr, nullptr, I, H, W, C, heads, shift));
+  else if (math == SV_MATH_BF16)
+    hipLaunchKernelGGL((win_attn_fwd_kernel<true, float>), grid, dim3(256), 0, s, win_args<float>(qkv, table, out, nullptr, nullptr, nullptr, I, H, W, C, heads, shift));
+  else
+    hipLaunchKernelGGL((win_attn_fwd_kernel<false, float>), grid, dim3(256), 0, s, win_args<float>(qkv, table, out, nullptr, nullptr, nullptr, I, H, W, C, heads, shift));
+  return check_launch("sv_window_attention_fwd");
+}
+
+extern "C" int sv_window_attention_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable,
+                                       int I, int H, int W, int C, int heads, int shift, int math, int act_dtype, void* stream) {
+  if (int rc = win_check(qkv, table, I, H, W, C, heads, shift, math, act_dtype)) return rc;
+  SV_REQUIRE(dout && dqkv && dtable && ((uintptr_t)dout & 15) == 0, "window_attention_bwd: null/unaligned argument");
+  const int ntasks = I * (H / 7) * (W / 7);
   const int wpb = math == SV_MATH_BF16 ? 4 : 2;   // waves per workgroup
   // several windows per wave (same head) so the bias gradient is reduced on chip; keep >= ~1024 waves in the grid
   int tpw = 1;
-  while (tpw < 8 && (long long)a.ntasks * heads / (tpw * 2) > 2048) tpw *= 2;
-  a.tasks_per_wave = tpw;
-  dim3 grid(cdiv(a.ntasks, wpb * tpw), heads);
-  if (math == SV_MATH_BF16) hipLaunchKernelGGL(win_attn_bwd_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(win_attn_bwd_kernel, grid, dim3(128), 0, (hipStream_t)stream, a);
+  while (tpw < 8 && (long long)ntasks * heads / (tpw * 2) > 2048) tpw *= 2;
+  dim3 grid(cdiv(ntasks, wpb * tpw), heads);
+  hipStream_t s = (hipStream_t)stream;
+  if (act_dtype == SV_BF16) {
+    WinArgsT<__bf16> a = win_args<__bf16>(qkv, table, nullptr, dout, dqkv, dtable, I, H, W, C, heads, shift);
+    a.tasks_per_wave = tpw;
+    hipLaunchKernelGGL(win_attn_bwd_bf16_kernel<__bf16>, grid, dim3(256), 0, s, a);
+  } else {
+    WinArgs a = win_args<float>(qkv, table, nullptr, dout, dqkv, dtable, I, H, W, C, heads, shift);
+    a.tasks_per_wave = tpw;
+    if (math == SV_MATH_BF16) hipLaunchKernelGGL(win_attn_bwd_bf16_kernel<float>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(win_attn_bwd_kernel, grid, dim3(128), 0, s, a);
+  }
   return check_launch("sv_window_attention_bwd");
 }
 
@@ -783,19 +812,24 @@ static int cva_check(int B, int V, int P, int R, int heads) {
   return SV_OK;
 }
 
-extern "C" int sv_cross_view_attention_fwd(const float* qkv, float* out, int B, int V, int P, int R, int heads, void* stream) {
+extern "C" int sv_cross_view_attention_fwd(const void* qkv, void* out, int B, int V, int P, int R, int heads, int act_dtype, void* stream) {
   SV_REQUIRE(qkv && out, "cross_view_attention_fwd: null argument");
+  SV_REQUIRE_ACT(act_dtype);
   if (int rc = cva_check(B, V, P, R, heads)) return rc;
-  CvaArgs a{qkv, out, nullptr, nullptr, B, V, P, R, heads, R / heads, 1.0f / sqrtf((float)(R / heads) * (float)V)};
-  hipLaunchKernelGGL(cva_attn_fwd_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
+  SV_DISPATCH_ACT(act_dtype,
+    CvaArgsT<AT> a{static_cast<const AT*>(qkv), static_cast<AT*>(out), nullptr, nullptr, B, V, P, R, heads, R / heads, 1.0f / sqrtf((float)(R / heads) * (float)V)};
+    hipLaunchKernelGGL(cva_attn_fwd_kernel<AT>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a););
   return check_launch("sv_cross_view_attention_fwd");
 }
 
-extern "C" int sv_cross_view_attention_bwd(const float* qkv, const float* dout, float* dqkv, int B, int V, int P, int R, int heads,
-                                           void* stream) {
+extern "C" int sv_cross_view_attention_bwd(const void* qkv, const void* dout, void* dqkv, int B, int V, int P, int R, int heads,
+                                           int act_dtype, void* stream) {
   SV_REQUIRE(qkv && dout && dqkv, "cross_view_attention_bwd: null argument");
+  SV_REQUIRE_ACT(act_dtype);
   if (int rc = cva_check(B, V, P, R, heads)) return rc;
-  CvaArgs a{qkv, nullptr, dout, dqkv, B, V, P, R, heads, R / heads, 1.0f / sqrtf((float)(R / heads) * (float)V)};
-  hipLaunchKernelGGL(cva_attn_bwd_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
+  SV_DISPATCH_ACT(act_dtype,
+    CvaArgsT<AT> a{static_cast<const AT*>(qkv), nullptr, static_cast<const AT*>(dout), static_cast<AT*>(dqkv), B, V, P, R, heads, R / heads,
+                   1.0f / sqrtf((float)(R / heads) * (float)V)};
+    hipLaunchKernelGGL(cva_attn_bwd_kernel<AT>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a););
   return check_launch("sv_cross_view_attention_bwd");
 }

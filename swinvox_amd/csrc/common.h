@@ -11,6 +11,47 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// ---- activation element types ---------------------------------------------------------------------------------
+// Activations (and activation gradients) live in HBM as fp32 (SV_F32) or bf16 (SV_BF16); arithmetic is always fp32.
+// Kernels are templated on the storage element AT and touch memory only through these helpers.
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v) { *p = (T)v; }
+__device__ __forceinline__ float4 ld4f(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4f(const __bf16* p) {
+  const bf16x4 b = *reinterpret_cast<const bf16x4*>(p);
+  return make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
+}
+__device__ __forceinline__ void st4f(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4f(__bf16* p, float4 v) {
+  bf16x4 b;
+  b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+  *reinterpret_cast<bf16x4*>(p) = b;
+}
+// raw 4-element vectors (no conversion) for the MFMA operand loaders
+template <typename T> struct V4;
+template <> struct V4<float> {
+  typedef float4 type;
+  static __device__ __forceinline__ type zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ type make(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+};
+template <> struct V4<__bf16> {
+  typedef bf16x4 type;
+  static __device__ __forceinline__ type zero() { type z; z[0] = z[1] = z[2] = z[3] = (__bf16)0.f; return z; }
+  static __device__ __forceinline__ type load(const __bf16* p) { return *reinterpret_cast<const bf16x4*>(p); }
+  static __device__ __forceinline__ type make(float a, float b, float c, float d) {
+    type z; z[0] = (__bf16)a; z[1] = (__bf16)b; z[2] = (__bf16)c; z[3] = (__bf16)d; return z;
+  }
+};
+
+// host-side dispatch on the activation dtype of a call: BODY sees the element type as AT
+#define SV_DISPATCH_ACT(act_dtype, ...)                  \
+  do {                                                   \
+    if ((act_dtype) == SV_BF16) { typedef __bf16 AT; __VA_ARGS__ } \
+    else { typedef float AT; __VA_ARGS__ }               \
+  } while (0)
+#define SV_REQUIRE_ACT(act_dtype) SV_REQUIRE((act_dtype) == SV_F32 || (act_dtype) == SV_BF16, "bad activation dtype %d", (int)(act_dtype))
+
 // error plumbing: every extern "C" entry returns 0 or a negative code and records a message
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);

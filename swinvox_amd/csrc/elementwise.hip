@@ -13,11 +13,12 @@ static inline unsigned grid_for(long long n, int per_block = 256, int cap = 8192
 }
 
 // dst[b][c][r] = src[b][r][c]; 32x32 LDS tiles (+1 pad), coalesced on both sides
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C,
+template <typename AT>
+__global__ __launch_bounds__(256) void transpose_kernel(const AT* __restrict__ src, AT* __restrict__ dst, int R, int C,
                                                         int lds_, int ldd, long long sb, long long db) {
-  __shared__ float tile[32][33];
-  const float* s = src + (size_t)blockIdx.z * sb;
-  float* d = dst + (size_t)blockIdx.z * db;
+  __shared__ AT tile[32][sizeof(AT) == 4 ? 33 : 34];
+  const AT* s = src + (size_t)blockIdx.z * sb;
+  AT* d = dst + (size_t)blockIdx.z * db;
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
 #pragma unroll
@@ -34,35 +35,49 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }
 
 // out[r, col_off + c] = a + b (+ c + d)
-__global__ __launch_bounds__(256) void add_n_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
-                                                    const float* __restrict__ d, float* __restrict__ out, long long M, int C, int ldo) {
+template <typename AT>
+__global__ __launch_bounds__(256) void add_n_kernel(const AT* __restrict__ a, const AT* __restrict__ b, const AT* __restrict__ c,
+                                                    const AT* __restrict__ d, AT* __restrict__ out, long long M, int C, int ldo) {
   const int cv = C >> 2;
   const long long total = M * cv;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / cv; const int col = (int)(i - r * cv) * 4;
     const size_t o = (size_t)r * C + col;
-    float4 v = *reinterpret_cast<const float4*>(a + o);
-    const float4 w = *reinterpret_cast<const float4*>(b + o);
+    float4 v = ld4f(a + o);
+    const float4 w = ld4f(b + o);
     v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-    if (c) { const float4 u = *reinterpret_cast<const float4*>(c + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-    if (d) { const float4 u = *reinterpret_cast<const float4*>(d + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-    *reinterpret_cast<float4*>(out + (size_t)r * ldo + col) = v;
+    if (c) { const float4 u = ld4f(c + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    if (d) { const float4 u = ld4f(d + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    st4f(out + (size_t)r * ldo + col, v);
   }
 }
 
-__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+template <typename AT>
+__global__ __launch_bounds__(256) void axpby_kernel(const AT* __restrict__ a, const AT* __restrict__ b, AT* __restrict__ out,
                                                     float alpha, float beta, long long n) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-    out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+    stf(out + i, alpha * ldf(a + i) + (b ? beta * ldf(b + i) : 0.f));
+}
+template <typename AT>
+__global__ __launch_bounds__(256) void axpby_vec_kernel(const AT* __restrict__ a, const AT* __restrict__ b, AT* __restrict__ out,
+                                                        float alpha, float beta, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 v = ld4f(a + i * 4);
+    v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+    if (b) { const float4 w = ld4f(b + i * 4); v.x += beta * w.x; v.y += beta * w.y; v.z += beta * w.z; v.w += beta * w.w; }
+    st4f(out + i * 4, v);
+  }
 }
 
 // out = dy * (y > 0)   (ReLU backward where no contraction epilogue can absorb it)
-__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out, long long n) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = y[i] > 0.f ? dy[i] : 0.f;
+template <typename AT>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const AT* __restrict__ dy, const AT* __restrict__ y, AT* __restrict__ out, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) stf(out + i, ldf(y + i) > 0.f ? ldf(dy + i) : 0.f);
 }
 
 // ---- ResNet stem max-pool 3x3 s2 p1 (NHWC); the arg-max tap is kept (first maximum in scan order, as torch)
-__global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
+template <typename AT>
+__global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const AT* __restrict__ x, AT* __restrict__ y, uint8_t* __restrict__ idx,
                                                             int N, int H, int W, int C, int Ho, int Wo) {
   const long long total = (long long)N * Ho * Wo * C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -75,27 +90,40 @@ __global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const float* __restr
       for (int kw = 0; kw < 3; ++kw) {
         const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
         if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-          const float v = x[(((size_t)n * H + ih) * W + iw) * C + c];
+          const float v = ldf(x + (((size_t)n * H + ih) * W + iw) * C + c);
           if (v > best) { best = v; bi = kh * 3 + kw; }
         }
       }
-    y[i] = best; idx[i] = (uint8_t)bi;
+    stf(y + i, best); idx[i] = (uint8_t)bi;
   }
 }
-__global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* __restrict__ dx,
+// gather form (no atomics, every input position written once): an input (ih, iw) belongs to the windows oh = (ih+1-kh)/2 with
+// kh of the parity of ih+1 (same along w) -> at most 2 x 2 candidate outputs, each contributing when its arg-max tap is this position
+template <typename AT>
+__global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const AT* __restrict__ dy, const uint8_t* __restrict__ idx, AT* __restrict__ dx,
                                                             int N, int H, int W, int C, int Ho, int Wo) {
-  const long long total = (long long)N * Ho * Wo * C;
+  const long long total = (long long)N * H * W * C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C); long long t = i / C;
-    const int ow = (int)(t % Wo); t /= Wo; const int oh = (int)(t % Ho); const int n = (int)(t / Ho);
-    const int bi = idx[i];
-    const int ih = oh * 2 - 1 + bi / 3, iw = ow * 2 - 1 + bi % 3;
-    atomicAdd(dx + (((size_t)n * H + ih) * W + iw) * C + c, dy[i]);
+    const int iw = (int)(t % W); t /= W; const int ih = (int)(t % H); const int n = (int)(t / H);
+    float acc = 0.f;
+    for (int kh = (ih + 1) & 1; kh < 3; kh += 2) {
+      const int oh = (ih + 1 - kh) >> 1;
+      if (ih + 1 - kh < 0 || oh >= Ho) continue;
+      for (int kw = (iw + 1) & 1; kw < 3; kw += 2) {
+        const int ow = (iw + 1 - kw) >> 1;
+        if (iw + 1 - kw < 0 || ow >= Wo) continue;
+        const size_t o = (((size_t)n * Ho + oh) * Wo + ow) * C + c;
+        if (idx[o] == kh * 3 + kw) acc += ldf(dy + o);
+      }
+    }
+    stf(dx + i, acc);
   }
 }
 
 // ---- 2x2 average pool (NHWC), output may be a column slice of a wider buffer
-__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
+template <typename AT>
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const AT* __restrict__ x, AT* __restrict__ y, int N, int H, int W, int C,
                                                            int ldy, int col_off) {
   const int Ho = H / 2, Wo = W / 2, cv = C / 4;
   const long long total = (long long)N * Ho * Wo * cv;
@@ -105,14 +133,15 @@ __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restri
     float4 s = make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + oh * 2 + (k >> 1)) * W + ow * 2 + (k & 1)) * C + c);
+      const float4 v = ld4f(x + (((size_t)n * H + oh * 2 + (k >> 1)) * W + ow * 2 + (k & 1)) * C + c);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     s.x *= 0.25f; s.y *= 0.25f; s.z *= 0.25f; s.w *= 0.25f;
-    *reinterpret_cast<float4*>(y + (((size_t)n * Ho + oh) * Wo + ow) * ldy + col_off + c) = s;
+    st4f(y + (((size_t)n * Ho + oh) * Wo + ow) * ldy + col_off + c, s);
   }
 }
-__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C,
+template <typename AT>
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const AT* __restrict__ dy, AT* __restrict__ dx, int N, int H, int W, int C,
                                                            int ldy, int col_off) {
   const int Ho = H / 2, Wo = W / 2, cv = C / 4;
   const long long total = (long long)N * H * W * cv;
@@ -121,28 +150,30 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
     const int w = (int)(t % W); t /= W; const int h = (int)(t % H); const int n = (int)(t / H);
     float4 v = make_float4(0, 0, 0, 0);
     if (h / 2 < Ho && w / 2 < Wo) {
-      v = *reinterpret_cast<const float4*>(dy + (((size_t)n * Ho + h / 2) * Wo + w / 2) * ldy + col_off + c);
+      v = ld4f(dy + (((size_t)n * Ho + h / 2) * Wo + w / 2) * ldy + col_off + c);
       v.x *= 0.25f; v.y *= 0.25f; v.z *= 0.25f; v.w *= 0.25f;
     }
-    *reinterpret_cast<float4*>(dx + (((size_t)n * H + h) * W + w) * C + c) = v;
+    st4f(dx + (((size_t)n * H + h) * W + w) * C + c, v);
   }
 }
 
 // ---- decoder seed: AdaptiveAvgPool2d 7->2 (bins [0:4],[3:7]) + depth replication -> [I,2,2,2,C]   (decoder.py:17,59-67)
-__global__ __launch_bounds__(256) void decoder_seed_fwd_kernel(const float* __restrict__ f, float* __restrict__ out, int I, int C) {
+template <typename AT>
+__global__ __launch_bounds__(256) void decoder_seed_fwd_kernel(const AT* __restrict__ f, AT* __restrict__ out, int I, int C) {
   const long long total = (long long)I * 4 * C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C); long long t = i / C;
     const int bx = (int)(t % 2); t /= 2; const int by = (int)(t % 2); const int n = (int)(t / 2);
     float s = 0.f;
     for (int r = by * 3; r < by * 3 + 4; ++r)
-      for (int q = bx * 3; q < bx * 3 + 4; ++q) s += f[(((size_t)n * 7 + r) * 7 + q) * C + c];
+      for (int q = bx * 3; q < bx * 3 + 4; ++q) s += ldf(f + (((size_t)n * 7 + r) * 7 + q) * C + c);
     s *= (1.f / 16.f);
-    out[((((size_t)n * 2 + 0) * 2 + by) * 2 + bx) * C + c] = s;
-    out[((((size_t)n * 2 + 1) * 2 + by) * 2 + bx) * C + c] = s;
+    stf(out + ((((size_t)n * 2 + 0) * 2 + by) * 2 + bx) * C + c, s);
+    stf(out + ((((size_t)n * 2 + 1) * 2 + by) * 2 + bx) * C + c, s);
   }
 }
-__global__ __launch_bounds__(256) void decoder_seed_bwd_kernel(const float* __restrict__ dout, float* __restrict__ df, int I, int C) {
+template <typename AT>
+__global__ __launch_bounds__(256) void decoder_seed_bwd_kernel(const AT* __restrict__ dout, AT* __restrict__ df, int I, int C) {
   const long long total = (long long)I * 49 * C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C); long long t = i / C;
@@ -151,13 +182,14 @@ __global__ __launch_bounds__(256) void decoder_seed_bwd_kernel(const float* __re
     for (int by = 0; by < 2; ++by)
       for (int bx = 0; bx < 2; ++bx)
         if (r >= by * 3 && r < by * 3 + 4 && q >= bx * 3 && q < bx * 3 + 4)
-          s += dout[((((size_t)n * 2 + 0) * 2 + by) * 2 + bx) * C + c] + dout[((((size_t)n * 2 + 1) * 2 + by) * 2 + bx) * C + c];
-    df[i] = s * (1.f / 16.f);
+          s += ldf(dout + ((((size_t)n * 2 + 0) * 2 + by) * 2 + bx) * C + c) + ldf(dout + ((((size_t)n * 2 + 1) * 2 + by) * 2 + bx) * C + c);
+    stf(df + i, s * (1.f / 16.f));
   }
 }
 
 // ---- MaxPool3d(2) with floor (33->16, 17->8, 9->4) on [N,D,H,W,C]
-__global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
+template <typename AT>
+__global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(const AT* __restrict__ x, AT* __restrict__ y, uint8_t* __restrict__ idx,
                                                             int N, int D, int H, int W, int C) {
   const int Do = D / 2, Ho = H / 2, Wo = W / 2;
   const long long total = (long long)N * Do * Ho * Wo * C;
@@ -167,13 +199,14 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(const float* __restr
     float best = -3.4e38f; int bi = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float v = x[((((size_t)n * D + od * 2 + (k >> 2)) * H + oh * 2 + ((k >> 1) & 1)) * W + ow * 2 + (k & 1)) * C + c];
+      const float v = ldf(x + ((((size_t)n * D + od * 2 + (k >> 2)) * H + oh * 2 + ((k >> 1) & 1)) * W + ow * 2 + (k & 1)) * C + c);
       if (v > best) { best = v; bi = k; }
     }
-    y[i] = best; idx[i] = (uint8_t)bi;
+    stf(y + i, best); idx[i] = (uint8_t)bi;
   }
 }
-__global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* __restrict__ dx,
+template <typename AT>
+__global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const AT* __restrict__ dy, const uint8_t* __restrict__ idx, AT* __restrict__ dx,
                                                             int N, int D, int H, int W, int C) {
   const int Do = D / 2, Ho = H / 2, Wo = W / 2;
   const long long total = (long long)N * D * H * W * C;
@@ -185,17 +218,18 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restr
     if (od < Do && oh < Ho && ow < Wo) {
       const size_t o = ((((size_t)n * Do + od) * Ho + oh) * Wo + ow) * C + c;
       const int k = ((d & 1) << 2) | ((h & 1) << 1) | (w & 1);
-      if (idx[o] == k) v = dy[o];
+      if (idx[o] == k) v = ldf(dy + o);
     }
-    dx[i] = v;
+    stf(dx + i, v);
   }
 }
 
 // ---- dropout (same kernel forward and backward: y = x * mask / keep, mask from (seed, element index))
-__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float p, uint32_t seed) {
+template <typename AT>
+__global__ __launch_bounds__(256) void dropout_kernel(const AT* __restrict__ x, AT* __restrict__ y, long long n, float p, uint32_t seed) {
   const float keep_inv = 1.f / (1.f - p);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-    y[i] = uniform01(seed, (uint64_t)i) < p ? 0.f : x[i] * keep_inv;
+    stf(y + i, uniform01(seed, (uint64_t)i) < p ? 0.f : ldf(x + i) * keep_inv);
 }
 // per-image drop-path factors: scale[i] = 0 or 1/keep
 __global__ void droppath_scale_kernel(float* __restrict__ scale, int I, float p, uint32_t seed) {
@@ -203,41 +237,57 @@ __global__ void droppath_scale_kernel(float* __restrict__ scale, int I, float p,
   if (i < I) scale[i] = uniform01(seed, (uint64_t)i) < p ? 0.f : 1.f / (1.f - p);
 }
 // y[row, :] = x[row, :] * scale[row / rows_per_scale]
-__global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ x, const float* __restrict__ scale, float* __restrict__ y,
+template <typename AT>
+__global__ __launch_bounds__(256) void rowscale_kernel(const AT* __restrict__ x, const float* __restrict__ scale, AT* __restrict__ y,
                                                        long long rows, int C, int rows_per_scale) {
   const long long total = rows * C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
-    y[i] = x[i] * scale[(i / C) / rows_per_scale];
+    stf(y + i, ldf(x + i) * scale[(i / C) / rows_per_scale]);
+}
+template <typename AT>
+__global__ __launch_bounds__(256) void rowscale_vec_kernel(const AT* __restrict__ x, const float* __restrict__ scale, AT* __restrict__ y,
+                                                           long long rows, int C, int rows_per_scale) {
+  const int cv = C >> 2;
+  const long long total = rows * cv;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const float sc = scale[(i / cv) / rows_per_scale];
+    float4 v = ld4f(x + i * 4);
+    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+    st4f(y + i * 4, v);
+  }
 }
 
 // ---- cross-view attention spatial path (cross_view_attention.py:26-32,68 and :110-120)
 // depthwise 2x2 stride-2 conv 7->3 (native weight [C,1,2,2])
-__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                                         float* __restrict__ y, int I, int C) {
+template <typename AT>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const AT* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                         AT* __restrict__ y, int I, int C) {
   const long long total = (long long)I * 9 * C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C); long long t = i / C;
     const int ox = (int)(t % 3); t /= 3; const int oy = (int)(t % 3); const int n = (int)(t / 3);
     float s = b ? b[c] : 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s += x[(((size_t)n * 7 + oy * 2 + (k >> 1)) * 7 + ox * 2 + (k & 1)) * C + c] * w[c * 4 + k];
-    y[i] = s;
+    for (int k = 0; k < 4; ++k) s += ldf(x + (((size_t)n * 7 + oy * 2 + (k >> 1)) * 7 + ox * 2 + (k & 1)) * C + c) * w[c * 4 + k];
+    stf(y + i, s);
   }
 }
 // dx (all 49 positions; row/col 6 receive 0)
-__global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+template <typename AT>
+__global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const AT* __restrict__ dy, const float* __restrict__ w, AT* __restrict__ dx,
                                                             int I, int C) {
   const long long total = (long long)I * 49 * C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C); long long t = i / C;
     const int xq = (int)(t % 7); t /= 7; const int yq = (int)(t % 7); const int n = (int)(t / 7);
     float v = 0.f;
-    if (yq < 6 && xq < 6) v = dy[(((size_t)n * 3 + yq / 2) * 3 + xq / 2) * C + c] * w[c * 4 + (yq & 1) * 2 + (xq & 1)];
-    dx[i] = v;
+    if (yq < 6 && xq < 6) v = ldf(dy + (((size_t)n * 3 + yq / 2) * 3 + xq / 2) * C + c) * w[c * 4 + (yq & 1) * 2 + (xq & 1)];
+    stf(dx + i, v);
   }
 }
 // dw[c][k], db[c]: one thread per (c,k) walks all images/positions (tiny tensors)
-__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+template <typename AT>
+__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const AT* __restrict__ dy, const AT* __restrict__ x, float* __restrict__ dw,
                                                            float* __restrict__ db, int I, int C) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= C * 4) return;
@@ -246,8 +296,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
   for (int n = 0; n < I; ++n)
     for (int o = 0; o < 9; ++o) {
       const int oy = o / 3, ox = o % 3;
-      const float g = dy[((size_t)n * 9 + o) * C + c];
-      s += g * x[(((size_t)n * 7 + oy * 2 + (k >> 1)) * 7 + ox * 2 + (k & 1)) * C + c];
+      const float g = ldf(dy + ((size_t)n * 9 + o) * C + c);
+      s += g * ldf(x + (((size_t)n * 7 + oy * 2 + (k >> 1)) * 7 + ox * 2 + (k & 1)) * C + c);
       sb += g;
     }
   dw[i] += s;
@@ -261,21 +311,23 @@ __device__ __forceinline__ void up_taps(int o, int& i0, int& i1, float& w0, floa
   i0 = (int)src; i1 = i0 < 2 ? i0 + 1 : 2;
   w1 = src - (float)i0; w0 = 1.f - w1;
 }
-__global__ __launch_bounds__(256) void upsample_add_fwd_kernel(const float* __restrict__ small, const float* __restrict__ x, int ldx,
-                                                               float* __restrict__ y, int I, int C) {
+template <typename AT>
+__global__ __launch_bounds__(256) void upsample_add_fwd_kernel(const AT* __restrict__ small, const AT* __restrict__ x, int ldx,
+                                                               AT* __restrict__ y, int I, int C) {
   const long long total = (long long)I * 49 * C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C); long long t = i / C;
     const int xq = (int)(t % 7); t /= 7; const int yq = (int)(t % 7); const int n = (int)(t / 7);
     int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
     up_taps(yq, y0, y1, wy0, wy1); up_taps(xq, x0, x1, wx0, wx1);
-    const float* s = small + (size_t)n * 9 * C + c;
-    const float v = wy0 * (wx0 * s[(y0 * 3 + x0) * C] + wx1 * s[(y0 * 3 + x1) * C]) +
-                    wy1 * (wx0 * s[(y1 * 3 + x0) * C] + wx1 * s[(y1 * 3 + x1) * C]);
-    y[i] = v + x[(((size_t)n * 7 + yq) * 7 + xq) * ldx + c];
+    const AT* s = small + (size_t)n * 9 * C + c;
+    const float v = wy0 * (wx0 * ldf(s + (y0 * 3 + x0) * C) + wx1 * ldf(s + (y0 * 3 + x1) * C)) +
+                    wy1 * (wx0 * ldf(s + (y1 * 3 + x0) * C) + wx1 * ldf(s + (y1 * 3 + x1) * C));
+    stf(y + i, v + ldf(x + (((size_t)n * 7 + yq) * 7 + xq) * ldx + c));
   }
 }
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dsmall, int I, int C) {
+template <typename AT>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const AT* __restrict__ dy, AT* __restrict__ dsmall, int I, int C) {
   const long long total = (long long)I * 9 * C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C); long long t = i / C;
@@ -288,38 +340,40 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
       for (int xq = 0; xq < 7; ++xq) {
         int x0, x1; float wx0, wx1; up_taps(xq, x0, x1, wx0, wx1);
         const float wx = (x0 == sx ? wx0 : 0.f) + (x1 == sx ? wx1 : 0.f);
-        if (wx != 0.f) acc += wy * wx * dy[(((size_t)n * 7 + yq) * 7 + xq) * C + c];
+        if (wx != 0.f) acc += wy * wx * ldf(dy + (((size_t)n * 7 + yq) * 7 + xq) * C + c);
       }
     }
-    dsmall[i] = acc;
+    stf(dsmall + i, acc);
   }
 }
 
 // ---- decoder head: ConvTranspose3d(8,1,k=1) + cat -> channels-last [M,12] raw (9 used) and [M] logits (decoder.py:45,83-94)
-__global__ __launch_bounds__(256) void decoder_head_fwd_kernel(const float* __restrict__ x8, const float* __restrict__ w, const float* __restrict__ bias,
-                                                               float* __restrict__ raw, float* __restrict__ vol, long long M) {
+template <typename AT>
+__global__ __launch_bounds__(256) void decoder_head_fwd_kernel(const AT* __restrict__ x8, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               AT* __restrict__ raw, AT* __restrict__ vol, long long M) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M; i += (long long)gridDim.x * 256) {
-    const float4 a = *reinterpret_cast<const float4*>(x8 + i * 8), b = *reinterpret_cast<const float4*>(x8 + i * 8 + 4);
+    const float4 a = ld4f(x8 + i * 8), b = ld4f(x8 + i * 8 + 4);
     float v = a.x * w[0] + a.y * w[1] + a.z * w[2] + a.w * w[3] + b.x * w[4] + b.y * w[5] + b.z * w[6] + b.w * w[7];
     if (bias) v += bias[0];
-    *reinterpret_cast<float4*>(raw + i * 12) = a;
-    *reinterpret_cast<float4*>(raw + i * 12 + 4) = b;
-    *reinterpret_cast<float4*>(raw + i * 12 + 8) = make_float4(v, 0.f, 0.f, 0.f);
-    vol[i] = v;
+    st4f(raw + i * 12, a);
+    st4f(raw + i * 12 + 4, b);
+    st4f(raw + i * 12 + 8, make_float4(v, 0.f, 0.f, 0.f));
+    stf(vol + i, v);
   }
 }
 // dx8[c] = draw[c] + w[c]*(draw[8] + dvol); dw[c] += sum x8[c]*(draw[8]+dvol); dbias += sum(draw[8]+dvol)
-__global__ __launch_bounds__(256) void decoder_head_bwd_kernel(const float* __restrict__ draw, const float* __restrict__ dvol, const float* __restrict__ x8,
-                                                               const float* __restrict__ w, float* __restrict__ dx8, float* __restrict__ dw,
+template <typename AT>
+__global__ __launch_bounds__(256) void decoder_head_bwd_kernel(const AT* __restrict__ draw, const AT* __restrict__ dvol, const AT* __restrict__ x8,
+                                                               const float* __restrict__ w, AT* __restrict__ dx8, float* __restrict__ dw,
                                                                float* __restrict__ dbias, long long M) {
   __shared__ float sc[4];
   float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M; i += (long long)gridDim.x * 256) {
-    const float4 ga = *reinterpret_cast<const float4*>(draw + i * 12), gb = *reinterpret_cast<const float4*>(draw + i * 12 + 4);
-    const float g = draw[i * 12 + 8] + (dvol ? dvol[i] : 0.f);
-    const float4 a = *reinterpret_cast<const float4*>(x8 + i * 8), b = *reinterpret_cast<const float4*>(x8 + i * 8 + 4);
-    *reinterpret_cast<float4*>(dx8 + i * 8) = make_float4(ga.x + w[0] * g, ga.y + w[1] * g, ga.z + w[2] * g, ga.w + w[3] * g);
-    *reinterpret_cast<float4*>(dx8 + i * 8 + 4) = make_float4(gb.x + w[4] * g, gb.y + w[5] * g, gb.z + w[6] * g, gb.w + w[7] * g);
+    const float4 ga = ld4f(draw + i * 12), gb = ld4f(draw + i * 12 + 4);
+    const float g = ldf(draw + i * 12 + 8) + (dvol ? ldf(dvol + i) : 0.f);
+    const float4 a = ld4f(x8 + i * 8), b = ld4f(x8 + i * 8 + 4);
+    st4f(dx8 + i * 8, make_float4(ga.x + w[0] * g, ga.y + w[1] * g, ga.z + w[2] * g, ga.w + w[3] * g));
+    st4f(dx8 + i * 8 + 4, make_float4(gb.x + w[4] * g, gb.y + w[5] * g, gb.z + w[6] * g, gb.w + w[7] * g));
     acc[0] += a.x * g; acc[1] += a.y * g; acc[2] += a.z * g; acc[3] += a.w * g;
     acc[4] += b.x * g; acc[5] += b.y * g; acc[6] += b.z * g; acc[7] += b.w * g; acc[8] += g;
   }
@@ -331,35 +385,37 @@ __global__ __launch_bounds__(256) void decoder_head_bwd_kernel(const float* __re
 }
 
 // ---- merger tail: softmax over the V views per voxel, weighted sum of the coarse volumes (merger.py:91-104)
-__global__ __launch_bounds__(256) void merge_views_fwd_kernel(const float* __restrict__ wl, const float* __restrict__ vol, float* __restrict__ out,
+template <typename AT>
+__global__ __launch_bounds__(256) void merge_views_fwd_kernel(const AT* __restrict__ wl, const AT* __restrict__ vol, AT* __restrict__ out,
                                                               int B, int V, int S) {
   const long long total = (long long)B * S;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int s = (int)(i % S); const long long b = i / S;
-    const float* wp = wl + (size_t)b * V * S + s; const float* vp = vol + (size_t)b * V * S + s;
+    const AT* wp = wl + (size_t)b * V * S + s; const AT* vp = vol + (size_t)b * V * S + s;
     float mx = -3.4e38f;
-    for (int v = 0; v < V; ++v) mx = fmaxf(mx, wp[(size_t)v * S]);
+    for (int v = 0; v < V; ++v) mx = fmaxf(mx, ldf(wp + (size_t)v * S));
     float den = 0.f, num = 0.f;
-    for (int v = 0; v < V; ++v) { const float e = expf(wp[(size_t)v * S] - mx); den += e; num += e * vp[(size_t)v * S]; }
-    out[i] = num / den;
+    for (int v = 0; v < V; ++v) { const float e = expf(ldf(wp + (size_t)v * S) - mx); den += e; num += e * ldf(vp + (size_t)v * S); }
+    stf(out + i, num / den);
   }
 }
-__global__ __launch_bounds__(256) void merge_views_bwd_kernel(const float* __restrict__ wl, const float* __restrict__ vol, const float* __restrict__ out,
-                                                              const float* __restrict__ dout, float* __restrict__ dwl, float* __restrict__ dvol,
+template <typename AT>
+__global__ __launch_bounds__(256) void merge_views_bwd_kernel(const AT* __restrict__ wl, const AT* __restrict__ vol, const AT* __restrict__ out,
+                                                              const AT* __restrict__ dout, AT* __restrict__ dwl, AT* __restrict__ dvol,
                                                               int B, int V, int S) {
   const long long total = (long long)B * S;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int s = (int)(i % S); const long long b = i / S;
     const size_t base = (size_t)b * V * S + s;
     float mx = -3.4e38f;
-    for (int v = 0; v < V; ++v) mx = fmaxf(mx, wl[base + (size_t)v * S]);
+    for (int v = 0; v < V; ++v) mx = fmaxf(mx, ldf(wl + base + (size_t)v * S));
     float den = 0.f;
-    for (int v = 0; v < V; ++v) den += expf(wl[base + (size_t)v * S] - mx);
-    const float g = dout[i], o = out[i], inv = 1.f / den;
+    for (int v = 0; v < V; ++v) den += expf(ldf(wl + base + (size_t)v * S) - mx);
+    const float g = ldf(dout + i), o = ldf(out + i), inv = 1.f / den;
     for (int v = 0; v < V; ++v) {
-      const float pv = expf(wl[base + (size_t)v * S] - mx) * inv;
-      dvol[base + (size_t)v * S] = g * pv;
-      dwl[base + (size_t)v * S] = pv * g * (vol[base + (size_t)v * S] - o);
+      const float pv = expf(ldf(wl + base + (size_t)v * S) - mx) * inv;
+      stf(dvol + base + (size_t)v * S, g * pv);
+      stf(dwl + base + (size_t)v * S, pv * g * (ldf(vol + base + (size_t)v * S) - o));
     }
   }
 }
@@ -372,6 +428,12 @@ __global__ __launch_bounds__(256) void mean_views_kernel(const float* __restrict
     for (int v = 0; v < V; ++v) a += vol[((size_t)b * V + v) * S + s];
     out[i] = a / V;
   }
+}
+
+// ---- storage conversion at the module boundaries (nn.Module inputs/outputs are fp32 torch tensors)
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (TD)(float)src[i];
 }
 
 // ---- BCE-with-logits (mean) forward + gradient in one pass (core/train.py:165,249,255)
@@ -417,74 +479,103 @@ __global__ __launch_bounds__(256) void iou_counts_kernel(const float* __restrict
 
 using namespace sv;
 #define STREAM ((hipStream_t)stream)
+#define CA(p) static_cast<const AT*>(p)
+#define MA(p) static_cast<AT*>(p)
 
-extern "C" int sv_transpose(const float* src, float* dst, int batch, int R, int C, int lds, int ldd, long long src_bstride,
-                            long long dst_bstride, void* stream) {
+extern "C" int sv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream) {
+  SV_REQUIRE(src && dst && n > 0, "cast: bad arguments");
+  SV_REQUIRE_ACT(src_dtype); SV_REQUIRE_ACT(dst_dtype);
+  const dim3 g(grid_for(n));
+  if (src_dtype == SV_F32 && dst_dtype == SV_BF16) hipLaunchKernelGGL((cast_kernel<float, __bf16>), g, dim3(256), 0, STREAM, (const float*)src, (__bf16*)dst, n);
+  else if (src_dtype == SV_BF16 && dst_dtype == SV_F32) hipLaunchKernelGGL((cast_kernel<__bf16, float>), g, dim3(256), 0, STREAM, (const __bf16*)src, (float*)dst, n);
+  else if (src_dtype == SV_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, dim3(256), 0, STREAM, (const float*)src, (float*)dst, n);
+  else hipLaunchKernelGGL((cast_kernel<__bf16, __bf16>), g, dim3(256), 0, STREAM, (const __bf16*)src, (__bf16*)dst, n);
+  return check_launch("sv_cast");
+}
+extern "C" int sv_transpose(const void* src, void* dst, int batch, int R, int C, int lds, int ldd, long long src_bstride,
+                            long long dst_bstride, int act_dtype, void* stream) {
   SV_REQUIRE(src && dst && batch > 0 && R > 0 && C > 0 && lds >= C && ldd >= R, "transpose: bad arguments");
   SV_REQUIRE(batch <= 65535, "transpose: batch %d too large", batch);
-  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32), batch), dim3(256), 0, STREAM, src, dst, R, C, lds, ldd, src_bstride, dst_bstride);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(transpose_kernel<AT>, dim3(cdiv(C, 32), cdiv(R, 32), batch), dim3(256), 0, STREAM, CA(src), MA(dst), R, C, lds, ldd,
+                                                src_bstride, dst_bstride););
   return check_launch("sv_transpose");
 }
-extern "C" int sv_add_n(const float* a, const float* b, const float* c, const float* d, float* out, long long M, int C, int ldo, void* stream) {
+extern "C" int sv_add_n(const void* a, const void* b, const void* c, const void* d, void* out, long long M, int C, int ldo, int act_dtype, void* stream) {
   SV_REQUIRE(a && b && out && M > 0 && C % 4 == 0 && ldo % 4 == 0 && ldo >= C, "add_n: bad arguments");
-  hipLaunchKernelGGL(add_n_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, STREAM, a, b, c, d, out, M, C, ldo);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(add_n_kernel<AT>, dim3(grid_for(M * (C / 4))), dim3(256), 0, STREAM, CA(a), CA(b), CA(c), CA(d), MA(out), M, C, ldo););
   return check_launch("sv_add_n");
 }
-extern "C" int sv_axpby(const float* a, const float* b, float* out, float alpha, float beta, long long n, void* stream) {
+extern "C" int sv_axpby(const void* a, const void* b, void* out, float alpha, float beta, long long n, int act_dtype, void* stream) {
   SV_REQUIRE(a && out && n > 0, "axpby: bad arguments");
-  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, STREAM, a, b, out, alpha, beta, n);
+  SV_REQUIRE_ACT(act_dtype);
+  const bool vec = n % 4 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0;
+  SV_DISPATCH_ACT(act_dtype,
+    if (vec) hipLaunchKernelGGL(axpby_vec_kernel<AT>, dim3(grid_for(n / 4)), dim3(256), 0, STREAM, CA(a), CA(b), MA(out), alpha, beta, n / 4);
+    else hipLaunchKernelGGL(axpby_kernel<AT>, dim3(grid_for(n)), dim3(256), 0, STREAM, CA(a), CA(b), MA(out), alpha, beta, n););
   return check_launch("sv_axpby");
 }
-extern "C" int sv_relu_bwd(const float* dy, const float* y, float* out, long long n, void* stream) {
+extern "C" int sv_relu_bwd(const void* dy, const void* y, void* out, long long n, int act_dtype, void* stream) {
   SV_REQUIRE(dy && y && out && n > 0, "relu_bwd: bad arguments");
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, STREAM, dy, y, out, n);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(relu_bwd_kernel<AT>, dim3(grid_for(n)), dim3(256), 0, STREAM, CA(dy), CA(y), MA(out), n););
   return check_launch("sv_relu_bwd");
 }
-extern "C" int sv_maxpool2d_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+extern "C" int sv_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int act_dtype, void* stream) {
   SV_REQUIRE(x && y && idx && N > 0 && H > 1 && W > 1 && C > 0, "maxpool2d_fwd: bad arguments");
+  SV_REQUIRE_ACT(act_dtype);
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool2d_fwd_kernel, dim3(grid_for((long long)N * Ho * Wo * C)), dim3(256), 0, STREAM, x, y, idx, N, H, W, C, Ho, Wo);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(maxpool2d_fwd_kernel<AT>, dim3(grid_for((long long)N * Ho * Wo * C)), dim3(256), 0, STREAM, CA(x), MA(y), idx, N, H, W, C, Ho, Wo););
   return check_launch("sv_maxpool2d_fwd");
 }
-extern "C" int sv_maxpool2d_bwd(const float* dy, const uint8_t* idx, float* dx_zeroed, int N, int H, int W, int C, void* stream) {
-  SV_REQUIRE(dy && idx && dx_zeroed && N > 0, "maxpool2d_bwd: bad arguments");
+extern "C" int sv_maxpool2d_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int act_dtype, void* stream) {
+  SV_REQUIRE(dy && idx && dx && N > 0, "maxpool2d_bwd: bad arguments");
+  SV_REQUIRE_ACT(act_dtype);
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool2d_bwd_kernel, dim3(grid_for((long long)N * Ho * Wo * C)), dim3(256), 0, STREAM, dy, idx, dx_zeroed, N, H, W, C, Ho, Wo);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(maxpool2d_bwd_kernel<AT>, dim3(grid_for((long long)N * H * W * C)), dim3(256), 0, STREAM, CA(dy), idx, MA(dx), N, H, W, C, Ho, Wo););
   return check_launch("sv_maxpool2d_bwd");
 }
-extern "C" int sv_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, int ldy, int col_off, void* stream) {
+extern "C" int sv_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int ldy, int col_off, int act_dtype, void* stream) {
   SV_REQUIRE(x && y && N > 0 && C % 4 == 0 && ldy % 4 == 0 && col_off % 4 == 0 && ldy >= col_off + C, "avgpool2_fwd: bad arguments");
-  hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(grid_for((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, STREAM, x, y, N, H, W, C, ldy, col_off);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(avgpool2_fwd_kernel<AT>, dim3(grid_for((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, STREAM, CA(x), MA(y), N, H, W, C, ldy, col_off););
   return check_launch("sv_avgpool2_fwd");
 }
-extern "C" int sv_avgpool2_bwd(const float* dy, float* dx, int N, int H, int W, int C, int ldy, int col_off, void* stream) {
+extern "C" int sv_avgpool2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int ldy, int col_off, int act_dtype, void* stream) {
   SV_REQUIRE(dy && dx && N > 0 && C % 4 == 0 && ldy % 4 == 0 && col_off % 4 == 0, "avgpool2_bwd: bad arguments");
-  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for((long long)N * H * W * (C / 4))), dim3(256), 0, STREAM, dy, dx, N, H, W, C, ldy, col_off);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(avgpool2_bwd_kernel<AT>, dim3(grid_for((long long)N * H * W * (C / 4))), dim3(256), 0, STREAM, CA(dy), MA(dx), N, H, W, C, ldy, col_off););
   return check_launch("sv_avgpool2_bwd");
 }
-extern "C" int sv_decoder_seed_fwd(const float* feat, float* out, int I, int C, void* stream) {
+extern "C" int sv_decoder_seed_fwd(const void* feat, void* out, int I, int C, int act_dtype, void* stream) {
   SV_REQUIRE(feat && out && I > 0 && C > 0, "decoder_seed_fwd: bad arguments");
-  hipLaunchKernelGGL(decoder_seed_fwd_kernel, dim3(grid_for((long long)I * 4 * C)), dim3(256), 0, STREAM, feat, out, I, C);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(decoder_seed_fwd_kernel<AT>, dim3(grid_for((long long)I * 4 * C)), dim3(256), 0, STREAM, CA(feat), MA(out), I, C););
   return check_launch("sv_decoder_seed_fwd");
 }
-extern "C" int sv_decoder_seed_bwd(const float* dout, float* dfeat, int I, int C, void* stream) {
+extern "C" int sv_decoder_seed_bwd(const void* dout, void* dfeat, int I, int C, int act_dtype, void* stream) {
   SV_REQUIRE(dout && dfeat && I > 0 && C > 0, "decoder_seed_bwd: bad arguments");
-  hipLaunchKernelGGL(decoder_seed_bwd_kernel, dim3(grid_for((long long)I * 49 * C)), dim3(256), 0, STREAM, dout, dfeat, I, C);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(decoder_seed_bwd_kernel<AT>, dim3(grid_for((long long)I * 49 * C)), dim3(256), 0, STREAM, CA(dout), MA(dfeat), I, C););
   return check_launch("sv_decoder_seed_bwd");
 }
-extern "C" int sv_maxpool3d_fwd(const float* x, float* y, uint8_t* idx, int N, int D, int H, int W, int C, void* stream) {
+extern "C" int sv_maxpool3d_fwd(const void* x, void* y, uint8_t* idx, int N, int D, int H, int W, int C, int act_dtype, void* stream) {
   SV_REQUIRE(x && y && idx && N > 0 && D > 1 && H > 1 && W > 1 && C > 0, "maxpool3d_fwd: bad arguments");
-  hipLaunchKernelGGL(maxpool3d_fwd_kernel, dim3(grid_for((long long)N * (D / 2) * (H / 2) * (W / 2) * C)), dim3(256), 0, STREAM, x, y, idx, N, D, H, W, C);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(maxpool3d_fwd_kernel<AT>, dim3(grid_for((long long)N * (D / 2) * (H / 2) * (W / 2) * C)), dim3(256), 0, STREAM, CA(x), MA(y), idx, N, D, H, W, C););
   return check_launch("sv_maxpool3d_fwd");
 }
-extern "C" int sv_maxpool3d_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int D, int H, int W, int C, void* stream) {
+extern "C" int sv_maxpool3d_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int D, int H, int W, int C, int act_dtype, void* stream) {
   SV_REQUIRE(dy && idx && dx && N > 0, "maxpool3d_bwd: bad arguments");
-  hipLaunchKernelGGL(maxpool3d_bwd_kernel, dim3(grid_for((long long)N * D * H * W * C)), dim3(256), 0, STREAM, dy, idx, dx, N, D, H, W, C);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(maxpool3d_bwd_kernel<AT>, dim3(grid_for((long long)N * D * H * W * C)), dim3(256), 0, STREAM, CA(dy), idx, MA(dx), N, D, H, W, C););
   return check_launch("sv_maxpool3d_bwd");
 }
-extern "C" int sv_dropout(const float* x, float* y, long long n, float p, uint32_t seed, void* stream) {
+extern "C" int sv_dropout(const void* x, void* y, long long n, float p, uint32_t seed, int act_dtype, void* stream) {
   SV_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
-  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, STREAM, x, y, n, p, seed);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(dropout_kernel<AT>, dim3(grid_for(n)), dim3(256), 0, STREAM, CA(x), MA(y), n, p, seed););
   return check_launch("sv_dropout");
 }
 extern "C" int sv_droppath_scale(float* scale, int I, float p, uint32_t seed, void* stream) {
@@ -492,52 +583,66 @@ extern "C" int sv_droppath_scale(float* scale, int I, float p, uint32_t seed, vo
   hipLaunchKernelGGL(droppath_scale_kernel, dim3(cdiv(I, 64)), dim3(64), 0, STREAM, scale, I, p, seed);
   return check_launch("sv_droppath_scale");
 }
-extern "C" int sv_rowscale(const float* x, const float* scale, float* y, long long rows, int C, int rows_per_scale, void* stream) {
+extern "C" int sv_rowscale(const void* x, const float* scale, void* y, long long rows, int C, int rows_per_scale, int act_dtype, void* stream) {
   SV_REQUIRE(x && scale && y && rows > 0 && C > 0 && rows_per_scale > 0, "rowscale: bad arguments");
-  hipLaunchKernelGGL(rowscale_kernel, dim3(grid_for(rows * C)), dim3(256), 0, STREAM, x, scale, y, rows, C, rows_per_scale);
+  SV_REQUIRE_ACT(act_dtype);
+  const bool vec = C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+  SV_DISPATCH_ACT(act_dtype,
+    if (vec) hipLaunchKernelGGL(rowscale_vec_kernel<AT>, dim3(grid_for(rows * (C / 4))), dim3(256), 0, STREAM, CA(x), scale, MA(y), rows, C, rows_per_scale);
+    else hipLaunchKernelGGL(rowscale_kernel<AT>, dim3(grid_for(rows * C)), dim3(256), 0, STREAM, CA(x), scale, MA(y), rows, C, rows_per_scale););
   return check_launch("sv_rowscale");
 }
-extern "C" int sv_dwconv2x2_fwd(const float* x, const float* w, const float* b, float* y, int I, int C, void* stream) {
+extern "C" int sv_dwconv2x2_fwd(const void* x, const float* w, const float* b, void* y, int I, int C, int act_dtype, void* stream) {
   SV_REQUIRE(x && w && y && I > 0 && C > 0, "dwconv2x2_fwd: bad arguments");
-  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(grid_for((long long)I * 9 * C)), dim3(256), 0, STREAM, x, w, b, y, I, C);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(dwconv_fwd_kernel<AT>, dim3(grid_for((long long)I * 9 * C)), dim3(256), 0, STREAM, CA(x), w, b, MA(y), I, C););
   return check_launch("sv_dwconv2x2_fwd");
 }
-extern "C" int sv_dwconv2x2_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int I, int C, void* stream) {
+extern "C" int sv_dwconv2x2_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int I, int C, int act_dtype, void* stream) {
   SV_REQUIRE(dy && x && w && dx && dw && I > 0 && C > 0, "dwconv2x2_bwd: bad arguments");
-  hipLaunchKernelGGL(dwconv_bwd_dx_kernel, dim3(grid_for((long long)I * 49 * C)), dim3(256), 0, STREAM, dy, w, dx, I, C);
-  hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(cdiv(C * 4, 256)), dim3(256), 0, STREAM, dy, x, dw, db, I, C);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype,
+    hipLaunchKernelGGL(dwconv_bwd_dx_kernel<AT>, dim3(grid_for((long long)I * 49 * C)), dim3(256), 0, STREAM, CA(dy), w, MA(dx), I, C);
+    hipLaunchKernelGGL(dwconv_bwd_w_kernel<AT>, dim3(cdiv(C * 4, 256)), dim3(256), 0, STREAM, CA(dy), CA(x), dw, db, I, C););
   return check_launch("sv_dwconv2x2_bwd");
 }
-extern "C" int sv_upsample3to7_add_fwd(const float* small, const float* x, int ldx, float* y, int I, int C, void* stream) {
+extern "C" int sv_upsample3to7_add_fwd(const void* small, const void* x, int ldx, void* y, int I, int C, int act_dtype, void* stream) {
   SV_REQUIRE(small && x && y && I > 0 && C > 0 && ldx >= C, "upsample3to7_add_fwd: bad arguments");
-  hipLaunchKernelGGL(upsample_add_fwd_kernel, dim3(grid_for((long long)I * 49 * C)), dim3(256), 0, STREAM, small, x, ldx, y, I, C);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(upsample_add_fwd_kernel<AT>, dim3(grid_for((long long)I * 49 * C)), dim3(256), 0, STREAM, CA(small), CA(x), ldx, MA(y), I, C););
   return check_launch("sv_upsample3to7_add_fwd");
 }
-extern "C" int sv_upsample3to7_bwd(const float* dy, float* dsmall, int I, int C, void* stream) {
+extern "C" int sv_upsample3to7_bwd(const void* dy, void* dsmall, int I, int C, int act_dtype, void* stream) {
   SV_REQUIRE(dy && dsmall && I > 0 && C > 0, "upsample3to7_bwd: bad arguments");
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for((long long)I * 9 * C)), dim3(256), 0, STREAM, dy, dsmall, I, C);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(upsample_bwd_kernel<AT>, dim3(grid_for((long long)I * 9 * C)), dim3(256), 0, STREAM, CA(dy), MA(dsmall), I, C););
   return check_launch("sv_upsample3to7_bwd");
 }
-extern "C" int sv_decoder_head_fwd(const float* x8, const float* w, const float* bias, float* raw12, float* vol, long long M, void* stream) {
+extern "C" int sv_decoder_head_fwd(const void* x8, const float* w, const float* bias, void* raw12, void* vol, long long M, int act_dtype, void* stream) {
   SV_REQUIRE(x8 && w && raw12 && vol && M > 0, "decoder_head_fwd: bad arguments");
-  hipLaunchKernelGGL(decoder_head_fwd_kernel, dim3(grid_for(M)), dim3(256), 0, STREAM, x8, w, bias, raw12, vol, M);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(decoder_head_fwd_kernel<AT>, dim3(grid_for(M)), dim3(256), 0, STREAM, CA(x8), w, bias, MA(raw12), MA(vol), M););
   return check_launch("sv_decoder_head_fwd");
 }
-extern "C" int sv_decoder_head_bwd(const float* draw12, const float* dvol, const float* x8, const float* w, float* dx8, float* dw, float* dbias,
-                                   long long M, void* stream) {
+extern "C" int sv_decoder_head_bwd(const void* draw12, const void* dvol, const void* x8, const float* w, void* dx8, float* dw, float* dbias,
+                                   long long M, int act_dtype, void* stream) {
   SV_REQUIRE(draw12 && x8 && w && dx8 && dw && M > 0, "decoder_head_bwd: bad arguments");
-  hipLaunchKernelGGL(decoder_head_bwd_kernel, dim3(grid_for(M, 256, 1024)), dim3(256), 0, STREAM, draw12, dvol, x8, w, dx8, dw, dbias, M);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(decoder_head_bwd_kernel<AT>, dim3(grid_for(M, 256, 1024)), dim3(256), 0, STREAM, CA(draw12), CA(dvol), CA(x8), w, MA(dx8), dw, dbias, M););
   return check_launch("sv_decoder_head_bwd");
 }
-extern "C" int sv_merge_views_fwd(const float* wlogit, const float* vol, float* out, int B, int V, int S, void* stream) {
+extern "C" int sv_merge_views_fwd(const void* wlogit, const void* vol, void* out, int B, int V, int S, int act_dtype, void* stream) {
   SV_REQUIRE(wlogit && vol && out && B > 0 && V > 0 && S > 0, "merge_views_fwd: bad arguments");
-  hipLaunchKernelGGL(merge_views_fwd_kernel, dim3(grid_for((long long)B * S)), dim3(256), 0, STREAM, wlogit, vol, out, B, V, S);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(merge_views_fwd_kernel<AT>, dim3(grid_for((long long)B * S)), dim3(256), 0, STREAM, CA(wlogit), CA(vol), MA(out), B, V, S););
   return check_launch("sv_merge_views_fwd");
 }
-extern "C" int sv_merge_views_bwd(const float* wlogit, const float* vol, const float* out, const float* dout, float* dwlogit, float* dvol,
-                                  int B, int V, int S, void* stream) {
+extern "C" int sv_merge_views_bwd(const void* wlogit, const void* vol, const void* out, const void* dout, void* dwlogit, void* dvol,
+                                  int B, int V, int S, int act_dtype, void* stream) {
   SV_REQUIRE(wlogit && vol && out && dout && dwlogit && dvol && B > 0 && V > 0 && S > 0, "merge_views_bwd: bad arguments");
-  hipLaunchKernelGGL(merge_views_bwd_kernel, dim3(grid_for((long long)B * S)), dim3(256), 0, STREAM, wlogit, vol, out, dout, dwlogit, dvol, B, V, S);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(merge_views_bwd_kernel<AT>, dim3(grid_for((long long)B * S)), dim3(256), 0, STREAM, CA(wlogit), CA(vol), CA(out), CA(dout),
+                                                MA(dwlogit), MA(dvol), B, V, S););
   return check_launch("sv_merge_views_bwd");
 }
 extern "C" int sv_mean_views(const float* vol, float* out, int B, int V, int S, void* stream) {

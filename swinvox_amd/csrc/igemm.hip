@@ -25,9 +25,9 @@ constexpr int PAD_BF16 = 8;  // bf16     (both = 16 bytes: keeps every row 16-by
 struct Geom {
   int N, Di, Hi, Wi, Do, Ho, Wo, Ci, Co, kd, kh, kw, sd, sh, sw, pd, ph, pw, ldi;
 };
-struct Epi {
-  const float* bias; const float* residual; int ldr; const float* row_scale; int rows_per_scale;
-  float* pre_act; double* stats; int act; float slope; const float* act_grad_src; int act_grad_kind; int ldc; int col_off;
+struct Epi {   // residual / pre_act / act_grad_src are activations (element type AT of the kernel)
+  const float* bias; const void* residual; int ldr; const float* row_scale; int rows_per_scale;
+  void* pre_act; double* stats; int act; float slope; const void* act_grad_src; int act_grad_kind; int ldc; int col_off;
 };
 struct ClassInfo {  // one output parity class of a transposed gather
   int o0[3];        // first output index of the class per axis
@@ -37,7 +37,7 @@ struct ClassInfo {  // one output parity class of a transposed gather
   int T[3];         // taps of the class per axis
 };
 struct IGemmArgs {
-  const float* x; const float* w; float* y;
+  const void* x; const float* w; void* y;   // x, y: activations (AT); w: fp32 packed weights
   Geom g; Epi e;
   int Ktot;         // row length of packed weights = taps_total * Ci
   ClassInfo cls[8];
@@ -66,6 +66,10 @@ __device__ __forceinline__ void store4(__bf16* dst, float4 v) {
   bf16x4 b;
   b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
   *reinterpret_cast<bf16x4*>(dst) = b;
+}
+__device__ __forceinline__ void store4(__bf16* dst, bf16x4 v) { *reinterpret_cast<bf16x4*>(dst) = v; }   // bf16 storage: no conversion
+__device__ __forceinline__ void store4(float* dst, bf16x4 v) {
+  *reinterpret_cast<float4*>(dst) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 
 // ---- MFMA over one K-step slab, operands stored [row][k] (k contiguous) ---------------------------
@@ -172,9 +176,12 @@ __device__ __forceinline__ void decode_row(int m, int c0, int c1, int c2, int& n
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------------
-template <bool BF16, bool TCONV, typename TL>
+template <bool BF16, bool TCONV, typename TL, typename AT>
 __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kernel(const IGemmArgs p) {
   typedef typename Cfg<BF16>::T LT;
+  typedef typename V4<AT>::type AV;
+  const AT* __restrict__ X = static_cast<const AT*>(p.x);
+  AT* __restrict__ Y = static_cast<AT*>(p.y);
   constexpr int BK = Cfg<BF16>::BK, LD = BK + Cfg<BF16>::PAD;
   constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT;
   constexpr int TPR = BK / 4;          // threads per tile row (one float4 each)
@@ -239,7 +246,8 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
     tw = tap % T2; const int t2 = tap / T2; th = t2 % T1; td = t2 / T1;
   }
 
-  float4 ra[NA], rbv[NB];
+  AV ra[NA];
+  float4 rbv[NB];
   auto load_tile = [&]() {   // loads the tile at the running k position, then advances the state by BK
     if (vec_ok) {
       const bool kok = td < T0;
@@ -251,9 +259,9 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
         const bool ok = kok && a_ok[i] && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi;
         if (ok) {
           const size_t off = ((((size_t)a_n[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + kc;
-          ra[i] = *reinterpret_cast<const float4*>(p.x + off);
+          ra[i] = V4<AT>::load(X + off);
         } else {
-          ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          ra[i] = V4<AT>::zero();
         }
       }
       // weights: [Co][taps_total][Ci]; TCONV maps the class-local tap to its kernel index
@@ -289,9 +297,9 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
           if constexpr (TCONV) { id = a_d[i] - td_; ih = a_h[i] - th_; iw = a_w[i] - tw_; }
           else { id = a_d[i] + td_; ih = a_h[i] + th_; iw = a_w[i] + tw_; }
           const bool ok = kk < K && a_ok[i] && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi;
-          v[j] = ok ? p.x[((((size_t)a_n[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + c] : 0.f;
+          v[j] = ok ? ldf(X + ((((size_t)a_n[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + c) : 0.f;
         }
-        ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+        ra[i] = V4<AT>::make(v[0], v[1], v[2], v[3]);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -390,18 +398,18 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
       const float sc = (e.residual && e.row_scale) ? e.row_scale[pos / e.rows_per_scale] : 1.f;
       if (vec_out) {   // Co % 4 == 0 => the whole float4 is in range
         if (e.act_grad_src) {
-          const float4 a = *reinterpret_cast<const float4*>(e.act_grad_src + o);
+          const float4 a = ld4f(static_cast<const AT*>(e.act_grad_src) + o);
           v[0] *= act_grad(a.x, e.act_grad_kind, e.slope); v[1] *= act_grad(a.y, e.act_grad_kind, e.slope);
           v[2] *= act_grad(a.z, e.act_grad_kind, e.slope); v[3] *= act_grad(a.w, e.act_grad_kind, e.slope);
         }
-        if (e.pre_act) *reinterpret_cast<float4*>(e.pre_act + o) = make_float4(v[0], v[1], v[2], v[3]);
+        if (e.pre_act) st4f(static_cast<AT*>(e.pre_act) + o, make_float4(v[0], v[1], v[2], v[3]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], e.act, e.slope);
         if (e.residual) {
-          const float4 r = *reinterpret_cast<const float4*>(e.residual + (size_t)pos * e.ldr + n0);
+          const float4 r = ld4f(static_cast<const AT*>(e.residual) + (size_t)pos * e.ldr + n0);
           v[0] = r.x + sc * v[0]; v[1] = r.y + sc * v[1]; v[2] = r.z + sc * v[2]; v[3] = r.w + sc * v[3];
         }
-        *reinterpret_cast<float4*>(p.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+        st4f(Y + o, make_float4(v[0], v[1], v[2], v[3]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
       } else {
@@ -409,11 +417,11 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
         for (int j = 0; j < 4; ++j) {
           if (n0 + j < g.Co) {
             float t = v[j];
-            if (e.act_grad_src) t *= act_grad(e.act_grad_src[o + j], e.act_grad_kind, e.slope);
-            if (e.pre_act) e.pre_act[o + j] = t;
+            if (e.act_grad_src) t *= act_grad(ldf(static_cast<const AT*>(e.act_grad_src) + o + j), e.act_grad_kind, e.slope);
+            if (e.pre_act) stf(static_cast<AT*>(e.pre_act) + o + j, t);
             t = apply_act(t, e.act, e.slope);
-            if (e.residual) t = e.residual[(size_t)pos * e.ldr + n0 + j] + sc * t;
-            p.y[o + j] = t;
+            if (e.residual) t = ldf(static_cast<const AT*>(e.residual) + (size_t)pos * e.ldr + n0 + j) + sc * t;
+            stf(Y + o + j, t);
             s1[j] += t; s2[j] += t * t;
           }
         }
@@ -447,14 +455,17 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
 // weight-gradient kernel
 // ------------------------------------------------------------------------------------------------
 struct WGradArgs {
-  const float* anchor; int lda; const float* gathered; float* out;   // out = dw (taps == 1) or the packed workspace
+  const void* anchor; int lda; const void* gathered; float* out;   // anchor/gathered: activations (AT); out = dw (taps == 1) or the packed workspace
   Geom g; int cg_valid; int rows_per_split; int Mrows; int direct;
   float* dbias;     // optional: dbias[ca] += sum_r anchor[r, ca] (bias gradient), folded into the k_out-tile-0 workgroups
 };
 
-template <bool BF16, typename TL>
+template <bool BF16, typename TL, typename AT>
 __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void wgrad_kernel(const WGradArgs p) {
   typedef typename Cfg<BF16>::T LT;
+  typedef typename V4<AT>::type AV;
+  const AT* __restrict__ ANC = static_cast<const AT*>(p.anchor);
+  const AT* __restrict__ GAT = static_cast<const AT*>(p.gathered);
   constexpr int BK = Cfg<BF16>::BK, PAD = Cfg<BF16>::PAD;
   constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT;
   constexpr int LDA = BM + PAD, LDB = BN + PAD;
@@ -491,50 +502,48 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void wgrad_kerne
 #pragma unroll
   for (int i = 0; i < B_PASS; ++i) decode_row(r_begin + b_r + B_RPP * i, g.Do, g.Ho, g.Wo, bn_[i], bd_[i], bh_[i], bw_[i]);
 
-  float4 ra[A_PASS], rbv[B_PASS];
+  AV ra[A_PASS], rbv[B_PASS];
   int r0 = r_begin;
   auto load_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       const int rl = a_r + A_RPP * i, r = r0 + rl;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      AV q = V4<AT>::zero();
       if (rl < BK && r < r_end) {
-        const float* src = p.anchor + (size_t)r * p.lda + ca0 + a_c;
+        const AT* src = ANC + (size_t)r * p.lda + ca0 + a_c;
         if (avec && ca0 + a_c + 3 < g.Co) {
-          const float4 q = *reinterpret_cast<const float4*>(src);
-          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+          q = V4<AT>::load(src);
         } else {
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) if (ca0 + a_c + j < g.Co) v[j] = src[j];
+          for (int j = 0; j < 4; ++j) if (ca0 + a_c + j < g.Co) v[j] = ldf(src + j);
+          q = V4<AT>::make(v[0], v[1], v[2], v[3]);
         }
       }
-      ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+      ra[i] = q;
     }
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
       const int rl = b_r + B_RPP * i, r = r0 + rl;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      AV q = V4<AT>::zero();
       if (rl < BK && r < r_end) {
         if (dense) {
           if (bvec) {
-            if (b_k < Kout) {
-              const float4 q = *reinterpret_cast<const float4*>(p.gathered + (size_t)r * g.ldi + b_k);
-              v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-            }
+            if (b_k < Kout) q = V4<AT>::load(GAT + (size_t)r * g.ldi + b_k);
           } else {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (b_k + j < Kout) v[j] = p.gathered[(size_t)r * g.ldi + b_k + j];
+            for (int j = 0; j < 4; ++j) if (b_k + j < Kout) v[j] = ldf(GAT + (size_t)r * g.ldi + b_k + j);
+            q = V4<AT>::make(v[0], v[1], v[2], v[3]);
           }
         } else {
           const int bd = bd_[i] * g.sd - g.pd, bh = bh_[i] * g.sh - g.ph, bw = bw_[i] * g.sw - g.pw;
           if (bvec) {
             const int id = bd + b_td, ih = bh + b_th, iw = bw + b_tw;
-            if (b_k < Kout && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi) {
-              const float4 q = *reinterpret_cast<const float4*>(
-                  p.gathered + ((((size_t)bn_[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + b_c);
-              v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-            }
+            if (b_k < Kout && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi)
+              q = V4<AT>::load(GAT + ((((size_t)bn_[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + b_c);
           } else {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int kk = b_k + j;
@@ -543,13 +552,14 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void wgrad_kerne
                 const int tw = tap % g.kw; const int t2 = tap / g.kw; const int th = t2 % g.kh; const int td = t2 / g.kh;
                 const int id = bd + td, ih = bh + th, iw = bw + tw;
                 if ((unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi)
-                  v[j] = p.gathered[((((size_t)bn_[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + c];
+                  v[j] = ldf(GAT + ((((size_t)bn_[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + c);
               }
             }
+            q = V4<AT>::make(v[0], v[1], v[2], v[3]);
           }
         }
       }
-      rbv[i] = make_float4(v[0], v[1], v[2], v[3]);
+      rbv[i] = q;
     }
     // advance the running row coordinates by BK
     r0 += BK;
@@ -653,7 +663,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long rows, int cols, int ld,
+template <typename AT>
+__global__ __launch_bounds__(256) void colsum_kernel(const AT* __restrict__ x, long long rows, int cols, int ld,
                                                      float* __restrict__ out, long long rows_per_block) {
   // block = 64 columns x 4 row-lanes; grid.x = column groups, grid.y = row splits
   __shared__ float red[4][64];
@@ -662,7 +673,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   const long long r0 = (long long)blockIdx.y * rows_per_block;
   long long r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
   float s = 0.f;
-  if (c < cols) for (long long r = r0 + rl; r < r1; r += 4) s += x[(size_t)r * ld + c];
+  if (c < cols) for (long long r = r0 + rl; r < r1; r += 4) s += ldf(x + (size_t)r * ld + c);
   red[rl][threadIdx.x & 63] = s;
   __syncthreads();
   if (rl == 0 && c < cols) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
@@ -681,7 +692,7 @@ static Epi to_epi(const sv_epilogue* e) {
         e->act, e->slope, e->act_grad_src, e->act_grad_kind, e->ldc, e->col_off};
   return q;
 }
-static int check_common(const sv_geom* g, const sv_epilogue* e, const void* in, const void* w, const void* out) {
+static int check_common(const sv_geom* g, const sv_epilogue* e, const void* in, const void* w, const void* out, int act_dtype) {
   SV_REQUIRE(g && e && in && w && out, "igemm: null argument");
   SV_REQUIRE(g->N > 0 && g->Ci > 0 && g->Co > 0, "igemm: N/Ci/Co must be positive (N=%d Ci=%d Co=%d)", g->N, g->Ci, g->Co);
   SV_REQUIRE(g->Di > 0 && g->Hi > 0 && g->Wi > 0 && g->Do > 0 && g->Ho > 0 && g->Wo > 0, "igemm: empty grid");
@@ -689,29 +700,33 @@ static int check_common(const sv_geom* g, const sv_epilogue* e, const void* in, 
   SV_REQUIRE(g->ldi >= g->Ci, "igemm: ldi (%d) < Ci (%d)", g->ldi, g->Ci);
   SV_REQUIRE(e->ldc >= e->col_off + g->Co, "igemm: ldc (%d) < col_off+Co (%d)", e->ldc, e->col_off + g->Co);
   SV_REQUIRE(!e->residual || e->ldr >= g->Co, "igemm: ldr (%d) < Co (%d)", e->ldr, g->Co);
-  SV_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)w & 15) == 0, "igemm: in/w must be 16-byte aligned");
+  SV_REQUIRE(((uintptr_t)in & (act_dtype == SV_BF16 ? 7 : 15)) == 0 && ((uintptr_t)w & 15) == 0, "igemm: in must be aligned to 4 elements, w to 16 bytes");
   SV_REQUIRE((long long)g->N * g->Do * g->Ho * g->Wo < (1ll << 31) && (long long)g->N * g->Di * g->Hi * g->Wi < (1ll << 31),
              "igemm: more than 2^31 positions");
   return SV_OK;
 }
 
 template <bool TCONV>
-static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, hipStream_t s) {
+static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, int act, hipStream_t s) {
   const int Co = a.g.Co;
   const bool bf = math == SV_MATH_BF16;
+#define SV_LAUNCH_IG(TL)                                                                                              \
+  do {                                                                                                                \
+    if (!bf) hipLaunchKernelGGL((igemm_kernel<false, TCONV, TL, float>), grid, dim3(TL::NTHR), 0, s, a);               \
+    else if (act == SV_BF16) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TL, __bf16>), grid, dim3(TL::NTHR), 0, s, a); \
+    else hipLaunchKernelGGL((igemm_kernel<true, TCONV, TL, float>), grid, dim3(TL::NTHR), 0, s, a);                    \
+  } while (0)
   if (Co <= 16) {
     dim3 grid(cdiv(M, TileNarrow::BM) * cdiv(Co, TileNarrow::BN), ncls);
-    if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileNarrow>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileNarrow>), grid, dim3(256), 0, s, a);
+    SV_LAUNCH_IG(TileNarrow);
   } else if (Co > 64 && (long long)cdiv(M, 128) * cdiv(Co, 128) * ncls >= 384) {   // 8-wave 128x128: one pass over A per 128 output columns
     dim3 grid(cdiv(M, TileBig::BM) * cdiv(Co, TileBig::BN), ncls);
-    if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileBig>), grid, dim3(TileBig::NTHR), 0, s, a);
-    else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileBig>), grid, dim3(TileBig::NTHR), 0, s, a);
+    SV_LAUNCH_IG(TileBig);
   } else {
     dim3 grid(cdiv(M, TileDefault::BM) * cdiv(Co, TileDefault::BN), ncls);
-    if (bf) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TileDefault>), grid, dim3(TileDefault::NTHR), 0, s, a);
-    else hipLaunchKernelGGL((igemm_kernel<false, TCONV, TileDefault>), grid, dim3(TileDefault::NTHR), 0, s, a);
+    SV_LAUNCH_IG(TileDefault);
   }
+#undef SV_LAUNCH_IG
 }
 
 typedef Tile<4, 2, 2, 2> WTileDefault;   // 128 anchor channels x 64 (tap, gathered channel), 8 waves
@@ -722,20 +737,24 @@ typedef Tile<2, 4, 4, 2> WTileWide;      // 128 x 128, 8 waves
 
 using namespace sv;
 
-extern "C" int sv_conv_gather(const float* in, const float* w, float* out, const sv_geom* g, const sv_epilogue* e,
-                              int math, void* stream) {
-  if (int rc = check_common(g, e, in, w, out)) return rc;
+extern "C" int sv_conv_gather(const void* in, const float* w, void* out, const sv_geom* g, const sv_epilogue* e,
+                              int math, int act_dtype, void* stream) {
+  if (int rc = check_common(g, e, in, w, out, act_dtype)) return rc;
+  SV_REQUIRE_ACT(act_dtype);
+  SV_REQUIRE(act_dtype == SV_F32 || math == SV_MATH_BF16, "igemm: bf16 activations require SV_MATH_BF16");
   IGemmArgs a{};
   a.x = in; a.w = w; a.y = out; a.g = to_geom(g); a.e = to_epi(e);
   a.Ktot = g->kd * g->kh * g->kw * g->Ci;
   const long long M = (long long)g->N * g->Do * g->Ho * g->Wo;
-  launch_igemm<false>(a, M, 1, math, (hipStream_t)stream);
+  launch_igemm<false>(a, M, 1, math, act_dtype, (hipStream_t)stream);
   return check_launch("sv_conv_gather");
 }
 
-extern "C" int sv_tconv_gather(const float* in, const float* w, float* out, const sv_geom* g, const sv_epilogue* e,
-                               int math, void* stream) {
-  if (int rc = check_common(g, e, in, w, out)) return rc;
+extern "C" int sv_tconv_gather(const void* in, const float* w, void* out, const sv_geom* g, const sv_epilogue* e,
+                               int math, int act_dtype, void* stream) {
+  if (int rc = check_common(g, e, in, w, out, act_dtype)) return rc;
+  SV_REQUIRE_ACT(act_dtype);
+  SV_REQUIRE(act_dtype == SV_F32 || math == SV_MATH_BF16, "igemm: bf16 activations require SV_MATH_BF16");
   SV_REQUIRE(g->sd <= 2 && g->sh <= 2 && g->sw <= 2, "tconv_gather: stride > 2 unsupported (%d,%d,%d)", g->sd, g->sh, g->sw);
   IGemmArgs a{};
   a.x = in; a.w = w; a.y = out; a.g = to_geom(g); a.e = to_epi(e);
@@ -762,7 +781,7 @@ extern "C" int sv_tconv_gather(const float* in, const float* w, float* out, cons
         a.cls[ncls++] = c;
       }
   if (maxM == 0) return SV_OK;
-  launch_igemm<true>(a, maxM, ncls, math, (hipStream_t)stream);
+  launch_igemm<true>(a, maxM, ncls, math, act_dtype, (hipStream_t)stream);
   return check_launch("sv_tconv_gather");
 }
 
@@ -771,12 +790,15 @@ extern "C" size_t sv_conv_wgrad_workspace_floats(const sv_geom* g) {
   return taps == 1 ? 0 : (size_t)g->Co * taps * g->Ci;
 }
 
-extern "C" int sv_conv_wgrad(const float* anchor, int lda, const float* gathered, float* dw, const sv_geom* g, int cg_valid,
-                             float* workspace, float* dbias, int math, void* stream) {
+extern "C" int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, float* dw, const sv_geom* g, int cg_valid,
+                             float* workspace, float* dbias, int math, int act_dtype, void* stream) {
   SV_REQUIRE(anchor && gathered && dw && g, "wgrad: null argument");
+  SV_REQUIRE_ACT(act_dtype);
+  SV_REQUIRE(act_dtype == SV_F32 || math == SV_MATH_BF16, "wgrad: bf16 activations require SV_MATH_BF16");
+  const int act = act_dtype;
   SV_REQUIRE(lda >= g->Co && g->ldi >= g->Ci && cg_valid > 0 && cg_valid <= g->Ci, "wgrad: bad strides (lda=%d Co=%d ldi=%d Ci=%d cg_valid=%d)",
              lda, g->Co, g->ldi, g->Ci, cg_valid);
-  SV_REQUIRE(((uintptr_t)anchor & 15) == 0 && ((uintptr_t)gathered & 15) == 0, "wgrad: operands must be 16-byte aligned");
+  SV_REQUIRE((((uintptr_t)anchor | (uintptr_t)gathered) & (act_dtype == SV_BF16 ? 7 : 15)) == 0, "wgrad: operands must be aligned to 4 elements");
   const long long Mll = (long long)g->N * g->Do * g->Ho * g->Wo;
   SV_REQUIRE(Mll > 0 && Mll < (1ll << 31), "wgrad: row count out of range");
   const int taps = g->kd * g->kh * g->kw;
@@ -808,16 +830,16 @@ extern "C" int sv_conv_wgrad(const float* anchor, int lda, const float* gathered
   a.rows_per_split = (int)rps;
   dim3 grid((unsigned)(cdiv(g->Co, BMw) * cdiv(Kout, BNw) * splits));
   const bool bf = math == SV_MATH_BF16;
-  if (narrow) {
-    if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileNarrow>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<false, WTileNarrow>), grid, dim3(256), 0, s, a);
-  } else if (wide) {
-    if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileWide>), grid, dim3(WTileWide::NTHR), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<false, WTileWide>), grid, dim3(WTileWide::NTHR), 0, s, a);
-  } else {
-    if (bf) hipLaunchKernelGGL((wgrad_kernel<true, WTileDefault>), grid, dim3(WTileDefault::NTHR), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<false, WTileDefault>), grid, dim3(WTileDefault::NTHR), 0, s, a);
-  }
+#define SV_LAUNCH_WG(TL)                                                                                         \
+  do {                                                                                                           \
+    if (!bf) hipLaunchKernelGGL((wgrad_kernel<false, TL, float>), grid, dim3(TL::NTHR), 0, s, a);                 \
+    else if (act == SV_BF16) hipLaunchKernelGGL((wgrad_kernel<true, TL, __bf16>), grid, dim3(TL::NTHR), 0, s, a); \
+    else hipLaunchKernelGGL((wgrad_kernel<true, TL, float>), grid, dim3(TL::NTHR), 0, s, a);                      \
+  } while (0)
+  if (narrow) SV_LAUNCH_WG(WTileNarrow);
+  else if (wide) SV_LAUNCH_WG(WTileWide);
+  else SV_LAUNCH_WG(WTileDefault);
+#undef SV_LAUNCH_WG
   if (!a.direct) {
     const long long total = (long long)g->Co * cg_valid * taps;
     int blocks = cdiv(total, 256); if (blocks > 2048) blocks = 2048;
@@ -837,14 +859,16 @@ extern "C" int sv_pack_weight(const float* src, float* dst, int A, int B, int T,
   return check_launch("sv_pack_weight");
 }
 
-extern "C" int sv_colsum(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* stream) {
+extern "C" int sv_colsum(const void* x, int rows, int cols, int ld, float* out, int accumulate, int act_dtype, void* stream) {
   SV_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "colsum: bad arguments");
+  SV_REQUIRE_ACT(act_dtype);
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * cols, s);
   const int cg = cdiv(cols, 64);
   int splits = 2048 / cg; if (splits < 1) splits = 1;
   const int maxs = cdiv(rows, 64); if (splits > maxs) splits = maxs;
   const long long rpb = (rows + splits - 1) / splits;
-  hipLaunchKernelGGL(colsum_kernel, dim3(cg, cdiv(rows, rpb)), dim3(256), 0, s, x, (long long)rows, cols, ld, out, rpb);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(colsum_kernel<AT>, dim3(cg, cdiv(rows, rpb)), dim3(256), 0, s, static_cast<const AT*>(x),
+                                                (long long)rows, cols, ld, out, rpb););
   return check_launch("sv_colsum");
 }

@@ -24,9 +24,9 @@ __device__ __forceinline__ size_t ln_src_off(long long row, int chunk, int C, co
   return ((size_t)(i * mm.H + 2 * y2 + hp) * mm.W + (2 * x2 + wp)) * mm.C0 + c;
 }
 
-template <bool MERGE>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float* __restrict__ y,
+template <bool MERGE, typename AT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const AT* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, AT* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      long long rows, int C, float eps, MergeMap mm) {
   const int lane = threadIdx.x & 63;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   for (int i = 0; i < LN_MAXV; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nchunk) {
-      v[i] = *reinterpret_cast<const float4*>(x + ln_src_off<MERGE>(row, ch, C, mm));
+      v[i] = ld4f(x + ln_src_off<MERGE>(row, ch, C, mm));
       s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
   }
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       float4 o;
       o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
       o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      *reinterpret_cast<float4*>(y + (size_t)row * C + ch * 4) = o;
+      st4f(y + (size_t)row * C + ch * 4, o);
     }
   }
 }
@@ -74,10 +74,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // stay in registers and only one atomic per column per workgroup reaches HBM.
 constexpr int LN_BWD_ROWS = 64;
 
-template <bool MERGE>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <bool MERGE, typename AT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, const AT* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
-                                                     const float* __restrict__ rstd_in, float* __restrict__ dx,
+                                                     const float* __restrict__ rstd_in, AT* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      long long rows, int C, MergeMap mm, int accumulate_dx) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2*C]
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int i = 0; i < LN_MAXV; ++i) {
       const int ch = lane + 64 * i;
       if (ch < nchunk) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + ln_src_off<MERGE>(row, ch, C, mm));
-        const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)row * C + ch * 4);
+        const float4 xv = ld4f(x + ln_src_off<MERGE>(row, ch, C, mm));
+        const float4 d = ld4f(dy + (size_t)row * C + ch * 4);
         xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd; xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
         g[i].x = d.x * gm[i].x; g[i].y = d.y * gm[i].y; g[i].z = d.z * gm[i].z; g[i].w = d.w * gm[i].w;
         s1 += g[i].x + g[i].y + g[i].z + g[i].w;
@@ -119,12 +119,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         float4 o;
         o.x = rstd * (g[i].x - m1 - xh[i].x * m2); o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
         o.z = rstd * (g[i].z - m1 - xh[i].z * m2); o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
-        float* dst = dx + ln_src_off<MERGE>(row, ch, C, mm);
+        AT* dst = dx + ln_src_off<MERGE>(row, ch, C, mm);
         if (accumulate_dx) {
-          const float4 old = *reinterpret_cast<const float4*>(dst);
+          const float4 old = ld4f(dst);
           o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
         }
-        *reinterpret_cast<float4*>(dst) = o;
+        st4f(dst, o);
       }
     }
   }
@@ -161,18 +161,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 // ------------------------------------------------------------------------------------------------
 constexpr int LNL_CHUNK = 4096;  // elements per workgroup in pass 1 (16 per thread)
 
-__global__ __launch_bounds__(256) void lnl_moments_kernel(const float* __restrict__ x, float* __restrict__ part, int L, int nchunks) {
+template <typename AT>
+__global__ __launch_bounds__(256) void lnl_moments_kernel(const AT* __restrict__ x, float* __restrict__ part, int L, int nchunks) {
   __shared__ float sc[4];
   const int img = blockIdx.y, ck = blockIdx.x;
   const int e0 = ck * LNL_CHUNK;
   int n = L - e0; if (n > LNL_CHUNK) n = LNL_CHUNK;
-  const float* src = x + (size_t)img * L + e0;
+  const AT* src = x + (size_t)img * L + e0;
   float4 v[4];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int e = (threadIdx.x + 256 * i) * 4;
-    if (e < n) { v[i] = *reinterpret_cast<const float4*>(src + e); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    if (e < n) { v[i] = ld4f(src + e); s += v[i].x + v[i].y + v[i].z + v[i].w; }
   }
   const float mean = block_sum<4>(s, sc) / n;
   float q = 0.f;
@@ -207,14 +208,15 @@ __global__ void lnl_finalize_kernel(const float* __restrict__ part, float* __res
   meanrstd[img * 2 + 1] = rsqrtf(m2_a / L + eps);
 }
 
-__global__ __launch_bounds__(256) void lnl_apply_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <typename AT>
+__global__ __launch_bounds__(256) void lnl_apply_kernel(const AT* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, const float* __restrict__ meanrstd,
-                                                        float* __restrict__ y, int L, float drop_p, uint32_t seed) {
+                                                        AT* __restrict__ y, int L, float drop_p, uint32_t seed) {
   const int img = blockIdx.y;
   const float mean = meanrstd[img * 2], rstd = meanrstd[img * 2 + 1];
   const float keep_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (int e = (blockIdx.x * 256 + threadIdx.x) * 4; e < L; e += gridDim.x * 1024) {
-    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)img * L + e);
+    const float4 xv = ld4f(x + (size_t)img * L + e);
     const float4 wv = *reinterpret_cast<const float4*>(w + e), bv = *reinterpret_cast<const float4*>(b + e);
     float o[4] = {(xv.x - mean) * rstd * wv.x + bv.x, (xv.y - mean) * rstd * wv.y + bv.y,
                   (xv.z - mean) * rstd * wv.z + bv.z, (xv.w - mean) * rstd * wv.w + bv.w};
@@ -222,12 +224,13 @@ __global__ __launch_bounds__(256) void lnl_apply_kernel(const float* __restrict_
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = uniform01(seed, (uint64_t)img * L + e + j) < drop_p ? 0.f : o[j] * keep_inv;
     }
-    *reinterpret_cast<float4*>(y + (size_t)img * L + e) = make_float4(o[0], o[1], o[2], o[3]);
+    st4f(y + (size_t)img * L + e, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
 // backward pass 1: per-image sums of g and g*xhat (g = dy*mask*w) -> sums[I][2] (atomics)
-__global__ __launch_bounds__(256) void lnl_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename AT>
+__global__ __launch_bounds__(256) void lnl_bwd_reduce_kernel(const AT* __restrict__ dy, const AT* __restrict__ x,
                                                              const float* __restrict__ w, const float* __restrict__ meanrstd,
                                                              double* __restrict__ sums, int L, float drop_p, uint32_t seed) {
   __shared__ float sc[4];
@@ -236,8 +239,8 @@ __global__ __launch_bounds__(256) void lnl_bwd_reduce_kernel(const float* __rest
   const float keep_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   float s1 = 0.f, s2 = 0.f;
   for (int e = (blockIdx.x * 256 + threadIdx.x) * 4; e < L; e += gridDim.x * 1024) {
-    const float4 dv = *reinterpret_cast<const float4*>(dy + (size_t)img * L + e);
-    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)img * L + e);
+    const float4 dv = ld4f(dy + (size_t)img * L + e);
+    const float4 xv = ld4f(x + (size_t)img * L + e);
     const float4 wv = *reinterpret_cast<const float4*>(w + e);
     const float d[4] = {dv.x, dv.y, dv.z, dv.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
@@ -254,9 +257,10 @@ __global__ __launch_bounds__(256) void lnl_bwd_reduce_kernel(const float* __rest
 }
 
 // backward pass 2: dx per element; dw/db accumulated over the images by the thread that owns element e
-__global__ __launch_bounds__(256) void lnl_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename AT>
+__global__ __launch_bounds__(256) void lnl_bwd_apply_kernel(const AT* __restrict__ dy, const AT* __restrict__ x,
                                                             const float* __restrict__ w, const float* __restrict__ meanrstd,
-                                                            const double* __restrict__ sums, float* __restrict__ dx,
+                                                            const double* __restrict__ sums, AT* __restrict__ dx,
                                                             float* __restrict__ dw, float* __restrict__ db, int L, int I,
                                                             float drop_p, uint32_t seed) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -266,11 +270,11 @@ __global__ __launch_bounds__(256) void lnl_bwd_apply_kernel(const float* __restr
   float aw = 0.f, ab = 0.f;
   for (int img = 0; img < I; ++img) {
     const float mean = meanrstd[img * 2], rstd = meanrstd[img * 2 + 1];
-    float dd = dy[(size_t)img * L + e];
+    float dd = ldf(dy + (size_t)img * L + e);
     if (drop_p > 0.f) dd = uniform01(seed, (uint64_t)img * L + e) < drop_p ? 0.f : dd * keep_inv;
-    const float xh = (x[(size_t)img * L + e] - mean) * rstd;
+    const float xh = (ldf(x + (size_t)img * L + e) - mean) * rstd;
     const float g = dd * wv;
-    dx[(size_t)img * L + e] = (float)((double)rstd * ((double)g - sums[img * 2] / L - (double)xh * (sums[img * 2 + 1] / L)));
+    stf(dx + (size_t)img * L + e, (float)((double)rstd * ((double)g - sums[img * 2] / L - (double)xh * (sums[img * 2 + 1] / L))));
     aw += dd * xh; ab += dd;
   }
   dw[e] += aw; db[e] += ab;
@@ -280,14 +284,15 @@ __global__ __launch_bounds__(256) void lnl_bwd_apply_kernel(const float* __restr
 // BatchNorm on channels-last [M, C] (row stride ld)
 // ------------------------------------------------------------------------------------------------
 // per-channel sum and sum of squares (when the producing contraction did not accumulate them itself)
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long long M, int C, int ld,
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const AT* __restrict__ x, long long M, int C, int ld,
                                                        double* __restrict__ sums, long long rows_per_block) {
   __shared__ double r1[4][64], r2[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const long long r0 = (long long)blockIdx.y * rows_per_block;
   long long r1e = r0 + rows_per_block; if (r1e > M) r1e = M;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C) for (long long r = r0 + rl; r < r1e; r += 4) { const double v = x[(size_t)r * ld + c]; s1 += v; s2 += v * v; }
+  if (c < C) for (long long r = r0 + rl; r < r1e; r += 4) { const double v = ldf(x + (size_t)r * ld + c); s1 += v; s2 += v * v; }
   r1[rl][threadIdx.x & 63] = s1; r2[rl][threadIdx.x & 63] = s2;
   __syncthreads();
   if (rl == 0 && c < C) {
@@ -325,42 +330,45 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
 }
 
 // y = act(x*scale[c] + shift[c] (+ residual))
-__global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, const float* __restrict__ res,
-                                                              int ldr, float* __restrict__ y, int ldy, long long M, int C,
+template <typename AT>
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(const AT* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const AT* __restrict__ res,
+                                                              int ldr, AT* __restrict__ y, int ldy, long long M, int C,
                                                               int act, float slope) {
   const int cv = C >> 2;  // C % 4 == 0 path
   const long long total = M * cv;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / cv; const int c = (int)(i - r * cv) * 4;
-    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+    const float4 xv = ld4f(x + (size_t)r * ldx + c);
     const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
     float o[4] = {xv.x * sc.x + sh.x, xv.y * sc.y + sh.y, xv.z * sc.z + sh.z, xv.w * sc.w + sh.w};
     if (res) {
-      const float4 rv = *reinterpret_cast<const float4*>(res + (size_t)r * ldr + c);
+      const float4 rv = ld4f(res + (size_t)r * ldr + c);
       o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j], act, slope);
-    *reinterpret_cast<float4*>(y + (size_t)r * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+    st4f(y + (size_t)r * ldy + c, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
-__global__ __launch_bounds__(256) void scale_shift_act_scalar_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
-                                                                     const float* __restrict__ shift, const float* __restrict__ res,
-                                                                     int ldr, float* __restrict__ y, int ldy, long long M, int C,
+template <typename AT>
+__global__ __launch_bounds__(256) void scale_shift_act_scalar_kernel(const AT* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, const AT* __restrict__ res,
+                                                                     int ldr, AT* __restrict__ y, int ldy, long long M, int C,
                                                                      int act, float slope) {
   const long long total = M * C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / C; const int c = (int)(i - r * C);
-    float o = x[(size_t)r * ldx + c] * scale[c] + shift[c];
-    if (res) o += res[(size_t)r * ldr + c];
-    y[(size_t)r * ldy + c] = apply_act(o, act, slope);
+    float o = ldf(x + (size_t)r * ldx + c) * scale[c] + shift[c];
+    if (res) o += ldf(res + (size_t)r * ldr + c);
+    stf(y + (size_t)r * ldy + c, apply_act(o, act, slope));
   }
 }
 
 // backward pass 1: per channel s1 = sum(dz'), s2 = sum(dz' * xhat), dz' = dz * act'(z) (mask from the OUTPUT z)
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz,
-                                                            const float* __restrict__ x, int ldx, const float* __restrict__ mean,
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const AT* __restrict__ dz, int lddz, const AT* __restrict__ z, int ldz,
+                                                            const AT* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, long long M, int C, int act, float slope,
                                                             double* __restrict__ sums, long long rows_per_block) {
   __shared__ double r1[4][64], r2[4][64];
@@ -375,9 +383,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       float d[4], xv[4], zv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        d[u] = dz[(size_t)(r + 4 * u) * lddz + c];
-        xv[u] = x[(size_t)(r + 4 * u) * ldx + c];
-        zv[u] = act != SV_ACT_NONE ? z[(size_t)(r + 4 * u) * ldz + c] : 1.f;
+        d[u] = ldf(dz + (size_t)(r + 4 * u) * lddz + c);
+        xv[u] = ldf(x + (size_t)(r + 4 * u) * ldx + c);
+        zv[u] = act != SV_ACT_NONE ? ldf(z + (size_t)(r + 4 * u) * ldz + c) : 1.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -386,9 +394,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       }
     }
     for (; r < r1e; r += 4) {
-      float d = dz[(size_t)r * lddz + c];
-      if (act != SV_ACT_NONE) d *= (z[(size_t)r * ldz + c] > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
-      s1 += (double)d; s2 += (double)(d * (x[(size_t)r * ldx + c] - mu) * rs);
+      float d = ldf(dz + (size_t)r * lddz + c);
+      if (act != SV_ACT_NONE) d *= (ldf(z + (size_t)r * ldz + c) > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
+      s1 += (double)d; s2 += (double)(d * (ldf(x + (size_t)r * ldx + c) - mu) * rs);
     }
   }
   r1[rl][threadIdx.x & 63] = s1; r2[rl][threadIdx.x & 63] = s2;
@@ -401,59 +409,61 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 // backward pass 2: dx = gamma*rstd*(dz' - s1/M - xhat*s2/M) (train) or dz'*gamma*rstd (eval); dres = dz' (optional);
 // block 0 also folds the sums into dgamma/dbeta
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz,
-                                                           const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const AT* __restrict__ dz, int lddz, const AT* __restrict__ z, int ldz,
+                                                           const AT* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const double* __restrict__ sums, long long M, int C, int act, float slope,
-                                                           int training, float* __restrict__ dx, int lddx, float* __restrict__ dres,
+                                                           int training, AT* __restrict__ dx, int lddx, AT* __restrict__ dres,
                                                            int lddres, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const long long total = M * C;
   const double invM = 1.0 / (double)M;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / C; const int c = (int)(i - r * C);
-    float d = dz[(size_t)r * lddz + c];
-    if (act != SV_ACT_NONE) d *= (z[(size_t)r * ldz + c] > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
-    if (dres) dres[(size_t)r * lddres + c] = d;
+    float d = ldf(dz + (size_t)r * lddz + c);
+    if (act != SV_ACT_NONE) d *= (ldf(z + (size_t)r * ldz + c) > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
+    if (dres) stf(dres + (size_t)r * lddres + c, d);
     const float rs = rstd[c];
     float o;
     if (training) {
       // double arithmetic for the mean-subtraction terms: sum_r dx must vanish to rounding, otherwise the residual is
       // amplified by every later reduction over positions (torch's CPU kernel evaluates this expression in double too)
-      const double xh = ((double)x[(size_t)r * ldx + c] - (double)mean[c]) * (double)rs;
+      const double xh = ((double)ldf(x + (size_t)r * ldx + c) - (double)mean[c]) * (double)rs;
       o = (float)((double)gamma[c] * (double)rs * ((double)d - sums[c] * invM - xh * (sums[C + c] * invM)));
     } else {
       o = d * gamma[c] * rs;
     }
-    dx[(size_t)r * lddx + c] = o;
+    stf(dx + (size_t)r * lddx + c, o);
   }
   if (blockIdx.x == 0)
     for (int c = threadIdx.x; c < C; c += 256) { dgamma[c] += (float)sums[C + c]; dbeta[c] += (float)sums[c]; }
 }
 
 // 16-byte variant of the above (C and every row stride multiples of 4): 4 channels per thread
-__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz,
-                                                               const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const AT* __restrict__ dz, int lddz, const AT* __restrict__ z, int ldz,
+                                                               const AT* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const double* __restrict__ sums, long long M, int C, int act, float slope,
-                                                               int training, float* __restrict__ dx, int lddx, float* __restrict__ dres,
+                                                               int training, AT* __restrict__ dx, int lddx, AT* __restrict__ dres,
                                                                int lddres, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int cv = C >> 2;
   const long long total = M * cv;
   const double invM = 1.0 / (double)M;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / cv; const int c = (int)(i - r * cv) * 4;
-    const float4 dv = *reinterpret_cast<const float4*>(dz + (size_t)r * lddz + c);
+    const float4 dv = ld4f(dz + (size_t)r * lddz + c);
     float d[4] = {dv.x, dv.y, dv.z, dv.w};
     if (act != SV_ACT_NONE) {
-      const float4 zv = *reinterpret_cast<const float4*>(z + (size_t)r * ldz + c);
+      const float4 zv = ld4f(z + (size_t)r * ldz + c);
       const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) d[j] *= (zz[j] > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
     }
-    if (dres) *reinterpret_cast<float4*>(dres + (size_t)r * lddres + c) = make_float4(d[0], d[1], d[2], d[3]);
+    if (dres) st4f(dres + (size_t)r * lddres + c, make_float4(d[0], d[1], d[2], d[3]));
     float o[4];
     if (training) {
-      const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+      const float4 xv = ld4f(x + (size_t)r * ldx + c);
       const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -465,81 +475,157 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __re
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = d[j] * gamma[c + j] * rstd[c + j];
     }
-    *reinterpret_cast<float4*>(dx + (size_t)r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+    st4f(dx + (size_t)r * lddx + c, make_float4(o[0], o[1], o[2], o[3]));
   }
   if (blockIdx.x == 0)
     for (int c = threadIdx.x; c < C; c += 256) { dgamma[c] += (float)sums[C + c]; dbeta[c] += (float)sums[c]; }
+}
+
+// vector variant of pass 1 (C and the row strides multiples of 4): a thread owns 4 adjacent channels of a strided row
+// subset; G = min(C/4, 64) column groups x 256/G row lanes per workgroup, row lanes folded through LDS
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __restrict__ dz, int lddz, const AT* __restrict__ z, int ldz,
+                                                                const AT* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, long long M, int C, int act, float slope,
+                                                                double* __restrict__ sums, long long rows_per_block, int G) {
+  __shared__ double red[256][9];   // [thread][8 partials] (+1 pad)
+  const int gq = threadIdx.x % G, rl = threadIdx.x / G, RL = 256 / G;
+  const int c = (blockIdx.x * G + gq) * 4;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  long long r1e = r0 + rows_per_block; if (r1e > M) r1e = M;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c < C && rl < RL) {
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+    const float neg = act == SV_ACT_LRELU ? slope : 0.f;
+    long long r = r0 + rl;
+    for (; r + RL < r1e; r += 2 * RL) {   // two rows in flight
+      const float4 d0 = ld4f(dz + (size_t)r * lddz + c), d1 = ld4f(dz + (size_t)(r + RL) * lddz + c);
+      const float4 x0 = ld4f(x + (size_t)r * ldx + c), x1 = ld4f(x + (size_t)(r + RL) * ldx + c);
+      float a0[4] = {d0.x, d0.y, d0.z, d0.w}, a1[4] = {d1.x, d1.y, d1.z, d1.w};
+      if (act != SV_ACT_NONE) {
+        const float4 z0 = ld4f(z + (size_t)r * ldz + c), z1 = ld4f(z + (size_t)(r + RL) * ldz + c);
+        const float q0[4] = {z0.x, z0.y, z0.z, z0.w}, q1[4] = {z1.x, z1.y, z1.z, z1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a0[j] *= q0[j] > 0.f ? 1.f : neg; a1[j] *= q1[j] > 0.f ? 1.f : neg; }
+      }
+      const float xa[4] = {x0.x, x0.y, x0.z, x0.w}, xb[4] = {x1.x, x1.y, x1.z, x1.w};
+      const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s1[j] += (double)a0[j] + (double)a1[j];
+        s2[j] += (double)(a0[j] * (xa[j] - mm[j]) * rr[j]) + (double)(a1[j] * (xb[j] - mm[j]) * rr[j]);
+      }
+    }
+    for (; r < r1e; r += RL) {
+      const float4 d0 = ld4f(dz + (size_t)r * lddz + c), x0 = ld4f(x + (size_t)r * ldx + c);
+      float a0[4] = {d0.x, d0.y, d0.z, d0.w};
+      if (act != SV_ACT_NONE) {
+        const float4 z0 = ld4f(z + (size_t)r * ldz + c);
+        const float q0[4] = {z0.x, z0.y, z0.z, z0.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a0[j] *= q0[j] > 0.f ? 1.f : neg;
+      }
+      const float xa[4] = {x0.x, x0.y, x0.z, x0.w}, mm[4] = {mu.x, mu.y, mu.z, mu.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] += (double)a0[j]; s2[j] += (double)(a0[j] * (xa[j] - mm[j]) * rr[j]); }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][4 + j] = s2[j]; }
+  __syncthreads();
+  // thread t < 8*G folds partial (t % 8) of column group (t / 8) over the row lanes
+  for (int t = threadIdx.x; t < 8 * G; t += 256) {
+    const int q = t >> 3, k = t & 7;
+    const int cc = (blockIdx.x * G + q) * 4 + (k & 3);
+    if (cc < C) {
+      double a = 0.0;
+      for (int l = 0; l < RL; ++l) a += red[l * G + q][k];
+      atomicAdd(sums + (k < 4 ? 0 : C) + cc, a);
+    }
+  }
 }
 
 }  // namespace sv
 
 using namespace sv;
 
-extern "C" int sv_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                                long long rows, int C, float eps, int merge_H, int merge_W, void* stream) {
+extern "C" int sv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                long long rows, int C, float eps, int merge_H, int merge_W, int act_dtype, void* stream) {
   SV_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0, "layernorm_fwd: null/empty argument");
   SV_REQUIRE(C % 4 == 0 && C <= 64 * 4 * LN_MAXV, "layernorm_fwd: C=%d must be a multiple of 4 and <= %d", C, 64 * 4 * LN_MAXV);
+  SV_REQUIRE_ACT(act_dtype);
   hipStream_t s = (hipStream_t)stream;
   if (merge_H > 0) {
     SV_REQUIRE(merge_H % 2 == 0 && merge_W % 2 == 0 && C % 16 == 0, "layernorm_fwd(merge): H,W must be even and C a multiple of 16");
     MergeMap mm{merge_H, merge_W, C / 4};
-    hipLaunchKernelGGL((ln_fwd_kernel<true>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps, mm);
+    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL((ln_fwd_kernel<true, AT>), dim3(cdiv(rows, 4)), dim3(256), 0, s, static_cast<const AT*>(x), gamma, beta,
+                                                  static_cast<AT*>(y), mean, rstd, rows, C, eps, mm););
   } else {
     MergeMap mm{0, 0, 0};
-    hipLaunchKernelGGL((ln_fwd_kernel<false>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps, mm);
+    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL((ln_fwd_kernel<false, AT>), dim3(cdiv(rows, 4)), dim3(256), 0, s, static_cast<const AT*>(x), gamma, beta,
+                                                  static_cast<AT*>(y), mean, rstd, rows, C, eps, mm););
   }
   return check_launch("sv_layernorm_fwd");
 }
 
-extern "C" int sv_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                float* dx, float* dgamma, float* dbeta, long long rows, int C, int merge_H, int merge_W,
-                                int accumulate_dx, void* stream) {
+extern "C" int sv_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                void* dx, float* dgamma, float* dbeta, long long rows, int C, int merge_H, int merge_W,
+                                int accumulate_dx, int act_dtype, void* stream) {
   SV_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "layernorm_bwd: null/empty argument");
   SV_REQUIRE(C % 4 == 0 && C <= 64 * 4 * LN_MAXV, "layernorm_bwd: C=%d unsupported", C);
+  SV_REQUIRE_ACT(act_dtype);
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = sizeof(float) * 2 * C;
   if (merge_H > 0) {
     MergeMap mm{merge_H, merge_W, C / 4};
-    hipLaunchKernelGGL((ln_bwd_kernel<true>), dim3(cdiv(rows, LN_BWD_ROWS)), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx);
+    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL((ln_bwd_kernel<true, AT>), dim3(cdiv(rows, LN_BWD_ROWS)), dim3(256), lds, s, static_cast<const AT*>(dy),
+                                                  static_cast<const AT*>(x), gamma, mean, rstd, static_cast<AT*>(dx), dgamma, dbeta, rows, C, mm, accumulate_dx););
   } else {
     MergeMap mm{0, 0, 0};
-    hipLaunchKernelGGL((ln_bwd_kernel<false>), dim3(cdiv(rows, LN_BWD_ROWS)), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx);
+    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL((ln_bwd_kernel<false, AT>), dim3(cdiv(rows, LN_BWD_ROWS)), dim3(256), lds, s, static_cast<const AT*>(dy),
+                                                  static_cast<const AT*>(x), gamma, mean, rstd, static_cast<AT*>(dx), dgamma, dbeta, rows, C, mm, accumulate_dx););
   }
   return check_launch("sv_layernorm_bwd");
 }
 
 extern "C" size_t sv_ln_image_workspace_floats(int I, int L) { return (size_t)I * cdiv(L, LNL_CHUNK) * 2; }
 
-extern "C" int sv_ln_image_fwd(const float* x, const float* w, const float* b, float* y, float* meanrstd, float* workspace,
-                               int I, int L, float eps, float drop_p, uint32_t seed, void* stream) {
+extern "C" int sv_ln_image_fwd(const void* x, const float* w, const float* b, void* y, float* meanrstd, float* workspace,
+                               int I, int L, float eps, float drop_p, uint32_t seed, int act_dtype, void* stream) {
   SV_REQUIRE(x && w && b && y && meanrstd && workspace && I > 0 && L > 0 && L % 4 == 0, "ln_image_fwd: bad arguments (I=%d L=%d)", I, L);
+  SV_REQUIRE_ACT(act_dtype);
   hipStream_t s = (hipStream_t)stream;
   const int nch = cdiv(L, LNL_CHUNK);
-  hipLaunchKernelGGL(lnl_moments_kernel, dim3(nch, I), dim3(256), 0, s, x, workspace, L, nch);
-  hipLaunchKernelGGL(lnl_finalize_kernel, dim3(cdiv(I, 64)), dim3(64), 0, s, workspace, meanrstd, L, nch, eps, I);
   int gx = cdiv(L, 1024); if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(lnl_apply_kernel, dim3(gx, I), dim3(256), 0, s, x, w, b, meanrstd, y, L, drop_p, seed);
+  SV_DISPATCH_ACT(act_dtype,
+    hipLaunchKernelGGL(lnl_moments_kernel<AT>, dim3(nch, I), dim3(256), 0, s, static_cast<const AT*>(x), workspace, L, nch);
+    hipLaunchKernelGGL(lnl_finalize_kernel, dim3(cdiv(I, 64)), dim3(64), 0, s, workspace, meanrstd, L, nch, eps, I);
+    hipLaunchKernelGGL(lnl_apply_kernel<AT>, dim3(gx, I), dim3(256), 0, s, static_cast<const AT*>(x), w, b, meanrstd, static_cast<AT*>(y), L, drop_p, seed););
   return check_launch("sv_ln_image_fwd");
 }
 
-extern "C" int sv_ln_image_bwd(const float* dy, const float* x, const float* w, const float* meanrstd, float* dx, float* dw,
-                               float* db, double* sums_ws, int I, int L, float drop_p, uint32_t seed, void* stream) {
+extern "C" int sv_ln_image_bwd(const void* dy, const void* x, const float* w, const float* meanrstd, void* dx, float* dw,
+                               float* db, double* sums_ws, int I, int L, float drop_p, uint32_t seed, int act_dtype, void* stream) {
   SV_REQUIRE(dy && x && w && meanrstd && dx && dw && db && sums_ws && I > 0 && L > 0 && L % 4 == 0, "ln_image_bwd: bad arguments");
+  SV_REQUIRE_ACT(act_dtype);
   hipStream_t s = (hipStream_t)stream;
   (void)hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * I, s);
   int gx = cdiv(L, 1024); if (gx > 32) gx = 32;
-  hipLaunchKernelGGL(lnl_bwd_reduce_kernel, dim3(gx, I), dim3(256), 0, s, dy, x, w, meanrstd, sums_ws, L, drop_p, seed);
-  hipLaunchKernelGGL(lnl_bwd_apply_kernel, dim3(cdiv(L, 256)), dim3(256), 0, s, dy, x, w, meanrstd, sums_ws, dx, dw, db, L, I, drop_p, seed);
+  SV_DISPATCH_ACT(act_dtype,
+    hipLaunchKernelGGL(lnl_bwd_reduce_kernel<AT>, dim3(gx, I), dim3(256), 0, s, static_cast<const AT*>(dy), static_cast<const AT*>(x), w, meanrstd, sums_ws, L, drop_p, seed);
+    hipLaunchKernelGGL(lnl_bwd_apply_kernel<AT>, dim3(cdiv(L, 256)), dim3(256), 0, s, static_cast<const AT*>(dy), static_cast<const AT*>(x), w, meanrstd, sums_ws,
+                       static_cast<AT*>(dx), dw, db, L, I, drop_p, seed););
   return check_launch("sv_ln_image_bwd");
 }
 
-extern "C" int sv_bn_stats(const float* x, long long M, int C, int ld, double* sums, void* stream) {
+extern "C" int sv_bn_stats(const void* x, long long M, int C, int ld, double* sums, int act_dtype, void* stream) {
   SV_REQUIRE(x && sums && M > 0 && C > 0 && ld >= C, "bn_stats: bad arguments");
+  SV_REQUIRE_ACT(act_dtype);
   const int cg = cdiv(C, 64);
   long long splits = 2048 / cg; if (splits < 1) splits = 1;
   const long long maxs = (M + 63) / 64; if (splits > maxs) splits = maxs;
   const long long rpb = (M + splits - 1) / splits;
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(cg, cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, x, M, C, ld, sums, rpb);
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(bn_stats_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, static_cast<const AT*>(x), M, C, ld, sums, rpb););
   return check_launch("sv_bn_stats");
 }
 
@@ -553,44 +639,66 @@ extern "C" int sv_bn_finalize(const double* sums, long long count, const float* 
   return check_launch("sv_bn_finalize");
 }
 
-extern "C" int sv_scale_shift_act(const float* x, int ldx, const float* scale, const float* shift, const float* residual, int ldr,
-                                  float* y, int ldy, long long M, int C, int act, float slope, void* stream) {
+// vector paths need every activation pointer aligned to 4 elements of the storage type
+static inline bool aligned4(int act_dtype, const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr,
+                            const void* e = nullptr) {
+  const uintptr_t m = act_dtype == SV_BF16 ? 7 : 15;
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e) & m) == 0;
+}
+
+extern "C" int sv_scale_shift_act(const void* x, int ldx, const float* scale, const float* shift, const void* residual, int ldr,
+                                  void* y, int ldy, long long M, int C, int act, float slope, int act_dtype, void* stream) {
   SV_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && ldx >= C && ldy >= C, "scale_shift_act: bad arguments");
+  SV_REQUIRE_ACT(act_dtype);
   hipStream_t s = (hipStream_t)stream;
-  const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (!residual || ldr % 4 == 0) &&
-                   (((uintptr_t)x | (uintptr_t)y | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)residual) & 15) == 0;
+  const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (!residual || ldr % 4 == 0) && aligned4(act_dtype, x, y, residual) &&
+                   (((uintptr_t)scale | (uintptr_t)shift) & 15) == 0;
   if (vec) {
     long long blocks = (M * (C / 4) + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(scale_shift_act_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, scale, shift, residual, ldr, y, ldy, M, C, act, slope);
+    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(scale_shift_act_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const AT*>(x), ldx, scale, shift,
+                                                  static_cast<const AT*>(residual), ldr, static_cast<AT*>(y), ldy, M, C, act, slope););
   } else {
     long long blocks = (M * C + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(scale_shift_act_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, scale, shift, residual, ldr, y, ldy, M, C, act, slope);
+    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(scale_shift_act_scalar_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const AT*>(x), ldx, scale, shift,
+                                                  static_cast<const AT*>(residual), ldr, static_cast<AT*>(y), ldy, M, C, act, slope););
   }
   return check_launch("sv_scale_shift_act");
 }
 
-extern "C" int sv_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const float* x, int ldx, const float* gamma,
+extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const void* x, int ldx, const float* gamma,
                          const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
-                         float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws, void* stream) {
+                         void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws, int act_dtype,
+                         void* stream) {
   SV_REQUIRE(dz && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && sums_ws && M > 0 && C > 0, "bn_bwd: null/empty argument");
   SV_REQUIRE(act == SV_ACT_NONE || z, "bn_bwd: the activation mask needs the forward output z");
+  SV_REQUIRE_ACT(act_dtype);
   hipStream_t s = (hipStream_t)stream;
   (void)hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * C, s);
-  const int cg = cdiv(C, 64);
-  long long splits = 2048 / cg; if (splits < 1) splits = 1;
-  const long long maxs = (M + 63) / 64; if (splits > maxs) splits = maxs;
-  const long long rpb = (M + splits - 1) / splits;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz, lddz, z, ldz, x, ldx, save_mean, save_rstd, M, C, act, slope, sums_ws, rpb);
   const bool vec = (C % 4 == 0) && (lddz % 4 == 0) && (ldx % 4 == 0) && (lddx % 4 == 0) && (!z || ldz % 4 == 0) && (!dres || lddres % 4 == 0) &&
-                   (((uintptr_t)dz | (uintptr_t)z | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
-  if (vec) {
-    long long blocks = (M * (C / 4) + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dz, lddz, z, ldz, x, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
-                       act, slope, training, dx, lddx, dres, lddres, dgamma, dbeta);
-  } else {
-    long long blocks = (M * C + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dz, lddz, z, ldz, x, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
-                       act, slope, training, dx, lddx, dres, lddres, dgamma, dbeta);
-  }
+                   aligned4(act_dtype, dz, z, x, dx, dres) && (((uintptr_t)save_mean | (uintptr_t)save_rstd) & 15) == 0;
+  SV_DISPATCH_ACT(act_dtype,
+    const AT* dz_ = static_cast<const AT*>(dz); const AT* z_ = static_cast<const AT*>(z); const AT* x_ = static_cast<const AT*>(x);
+    AT* dx_ = static_cast<AT*>(dx); AT* dres_ = static_cast<AT*>(dres);
+    if (vec) {
+      const int G = C / 4 < 64 ? C / 4 : 64, RL = 256 / G;
+      const int cg = cdiv(C / 4, G);
+      long long splits = 2048 / cg; if (splits < 1) splits = 1;
+      const long long maxs = (M + 2 * RL - 1) / (2 * RL); if (splits > maxs) splits = maxs;
+      const long long rpb = (M + splits - 1) / splits;
+      hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope,
+                         sums_ws, rpb, G);
+      long long blocks = (M * (C / 4) + 255) / 256; if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
+                         act, slope, training, dx_, lddx, dres_, lddres, dgamma, dbeta);
+    } else {
+      const int cg = cdiv(C, 64);
+      long long splits = 2048 / cg; if (splits < 1) splits = 1;
+      const long long maxs = (M + 63) / 64; if (splits > maxs) splits = maxs;
+      const long long rpb = (M + splits - 1) / splits;
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope, sums_ws, rpb);
+      long long blocks = (M * C + 255) / 256; if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
+                         act, slope, training, dx_, lddx, dres_, lddres, dgamma, dbeta);
+    });
   return check_launch("sv_bn_bwd");
 }

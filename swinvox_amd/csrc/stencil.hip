@@ -19,18 +19,19 @@ constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;  // with halo
 constexpr int HPOS = HZ * HY * HX;                    // 600 positions
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 
-struct StencilArgs {
-  const float* x; int ldx; int cin_load;      // input positions [I*D*H*W][ldx], cin_load (multiple of 4, <= 16*G) floats loaded per position
+template <typename AT>
+struct StencilArgsT {                         // AT = storage element of the activations (x, out, residual)
+  const AT* x; int ldx; int cin_load;         // input positions [I*D*H*W][ldx], cin_load (multiple of 4, <= 16*G) elements loaded per position
   const __bf16* w;                            // packed weights [NT*16][27][16*G]
-  const float* bias; float* out; int ldc; int col_off; int cout;   // columns written: n < cout
-  const float* residual; int ldr;             // optional: out = residual + val (same column window)
+  const float* bias; AT* out; int ldc; int col_off; int cout;   // columns written: n < cout
+  const AT* residual; int ldr;                // optional: out = residual + val (same column window)
   double* stats;                              // optional [SV_BN_SLOTS][2*cout]
   int I, D, H, W;
 };
 
 // stage the halo brick of one tile into LDS as bf16 [HPOS][16*G]; out-of-volume positions and channels >= cin_load are zero
-template <int G>
-__device__ __forceinline__ void load_halo(__bf16* Xs, const float* x, int ldx, int cin_load, int img, int z0, int y0, int x0,
+template <int G, typename AT>
+__device__ __forceinline__ void load_halo(__bf16* Xs, const AT* x, int ldx, int cin_load, int img, int z0, int y0, int x0,
                                           int D, int H, int W, int tid) {
   constexpr int C = 16 * G, V4 = C / 4;
   for (int i = tid; i < HPOS * V4; i += 256) {
@@ -39,15 +40,13 @@ __device__ __forceinline__ void load_halo(__bf16* Xs, const float* x, int ldx, i
     const int z = z0 - 1 + hz, y = y0 - 1 + hy, xx = x0 - 1 + hx;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (v * 4 < cin_load && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W)
-      q = *reinterpret_cast<const float4*>(x + ((((size_t)img * D + z) * H + y) * W + xx) * (size_t)ldx + v * 4);
-    bf16x4 b;
-    b[0] = (__bf16)q.x; b[1] = (__bf16)q.y; b[2] = (__bf16)q.z; b[3] = (__bf16)q.w;
-    *reinterpret_cast<bf16x4*>(Xs + h * C + v * 4) = b;
+      q = ld4f(x + ((((size_t)img * D + z) * H + y) * W + xx) * (size_t)ldx + v * 4);
+    st4f(Xs + h * C + v * 4, q);
   }
 }
 
-template <int G, int NT>
-__global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgs p) {
+template <int G, int NT, typename AT>
+__global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgsT<AT> p) {
   constexpr int C = 16 * G, KTOT = 27 * C, KPAD = (KTOT + 31) / 32 * 32, NSTEP = KPAD / 32;
   __shared__ __attribute__((aligned(16))) __bf16 Xs[HPOS * C];
   __shared__ __attribute__((aligned(16))) __bf16 Ws[NT * 16 * KPAD];
@@ -67,7 +66,7 @@ __global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgs p) 
     for (int j = 0; j < 8; ++j) v[j] = (k + j < KTOT) ? p.w[(size_t)n * KTOT + k + j] : (__bf16)0.f;
     *reinterpret_cast<bf16x8*>(Ws + n * KPAD + k) = v;
   }
-  load_halo<G>(Xs, p.x, p.ldx, p.cin_load, img, z0, y0, x0, p.D, p.H, p.W, tid);
+  load_halo<G, AT>(Xs, p.x, p.ldx, p.cin_load, img, z0, y0, x0, p.D, p.H, p.W, tid);
   __syncthreads();
 
   // this wave: z-slice `wave`; M-tile mt = rows y = 2mt, 2mt+1; fragment row r = lane&15 -> (yy = r>>3, xx = r&7)
@@ -114,8 +113,8 @@ __global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgs p) 
         if (nok) {
           const size_t pos = (((size_t)img * p.D + z) * p.H + y) * p.W + x;
           float v = acc[mt][nt][j] + bias;
-          if (p.residual) v += p.residual[pos * p.ldr + n];
-          p.out[pos * p.ldc + p.col_off + n] = v;
+          if (p.residual) v += ldf(p.residual + pos * p.ldr + n);
+          stf(p.out + pos * p.ldc + p.col_off + n, v);
           s1 += v; s2 += v * v;
         }
       }
@@ -138,17 +137,18 @@ __global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgs p) 
   }
 }
 
-struct StencilWArgs {
-  const float* x; int ldx; int cin_load;     // gathered operand (conv input), memory channels = 16*G (zero-padded)
-  const float* dy; int lddy; int cout_load;  // anchor operand (output gradient), <= 16 memory channels
+template <typename AT>
+struct StencilWArgsT {
+  const AT* x; int ldx; int cin_load;        // gathered operand (conv input), memory channels = 16*G (zero-padded)
+  const AT* dy; int lddy; int cout_load;     // anchor operand (output gradient), <= 16 memory channels
   float* dw;                                 // native [cout][cin][27], accumulated with atomics
   int cout, cin;                             // real channel counts
   int c_stride, c_valid;                     // memory channel c -> real channel (c / c_stride) * c_valid + c % c_stride, valid if c % c_stride < c_valid
   int I, D, H, W, ntiles;
 };
 
-template <int G>
-__global__ __launch_bounds__(256) void stencil3_wgrad_kernel(const StencilWArgs p) {
+template <int G, typename AT>
+__global__ __launch_bounds__(256) void stencil3_wgrad_kernel(const StencilWArgsT<AT> p) {
   constexpr int C = 16 * G;
   __shared__ __attribute__((aligned(16))) __bf16 Xs[HPOS * C];
   __shared__ __attribute__((aligned(16))) __bf16 Ds[TZ * TY * TX * 16];
@@ -168,16 +168,14 @@ __global__ __launch_bounds__(256) void stencil3_wgrad_kernel(const StencilWArgs 
     const int bx = t % tx; t /= tx; const int by = t % ty; t /= ty; const int bz = t % tz; const int img = t / tz;
     const int z0 = bz * TZ, y0 = by * TY, x0 = bx * TX;
     __syncthreads();   // previous tile's LDS reads are done
-    load_halo<G>(Xs, p.x, p.ldx, p.cin_load, img, z0, y0, x0, p.D, p.H, p.W, tid);
+    load_halo<G, AT>(Xs, p.x, p.ldx, p.cin_load, img, z0, y0, x0, p.D, p.H, p.W, tid);
     for (int i = tid; i < TZ * TY * TX * 4; i += 256) {     // dy brick -> [voxel][16] bf16
       const int v = i >> 2, c4 = i & 3;
       const int xx = v % TX; const int t2 = v / TX; const int yy = t2 % TY; const int zz = t2 / TY;
       float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c4 * 4 < p.cout_load)
-        qv = *reinterpret_cast<const float4*>(p.dy + ((((size_t)img * p.D + z0 + zz) * p.H + y0 + yy) * p.W + x0 + xx) * (size_t)p.lddy + c4 * 4);
-      bf16x4 b;
-      b[0] = (__bf16)qv.x; b[1] = (__bf16)qv.y; b[2] = (__bf16)qv.z; b[3] = (__bf16)qv.w;
-      *reinterpret_cast<bf16x4*>(Ds + v * 16 + c4 * 4) = b;
+        qv = ld4f(p.dy + ((((size_t)img * p.D + z0 + zz) * p.H + y0 + yy) * p.W + x0 + xx) * (size_t)p.lddy + c4 * 4);
+      st4f(Ds + v * 16 + c4 * 4, qv);
     }
     __syncthreads();
     // 8 chunks of 32 voxels: chunk = (z, half); k = 8*g + j  <->  (y = 4*half + g, x = j)
@@ -237,38 +235,47 @@ static int stencil_check(int I, int D, int H, int W) {
   return SV_OK;
 }
 
-extern "C" int sv_stencil3_fwd(const float* x, int ldx, int cin_load, int groups, const void* w_bf16, int ntiles16,
-                               const float* bias, float* out, int ldc, int col_off, int cout, const float* residual, int ldr,
-                               double* stats, int I, int D, int H, int W, void* stream) {
+extern "C" int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups, const void* w_bf16, int ntiles16,
+                               const float* bias, void* out, int ldc, int col_off, int cout, const void* residual, int ldr,
+                               double* stats, int I, int D, int H, int W, int act_dtype, void* stream) {
   SV_REQUIRE(x && w_bf16 && out, "stencil3_fwd: null argument");
+  SV_REQUIRE_ACT(act_dtype);
   if (int rc = stencil_check(I, D, H, W)) return rc;
   SV_REQUIRE(cin_load % 4 == 0 && cin_load <= 16 * groups && ldx % 4 == 0 && ldx >= cin_load, "stencil3_fwd: bad input channels (cin_load=%d ldx=%d groups=%d)", cin_load, ldx, groups);
   SV_REQUIRE(cout > 0 && cout <= 16 * ntiles16 && ldc >= col_off + cout, "stencil3_fwd: bad output window");
-  SV_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_bf16 & 15) == 0, "stencil3_fwd: operands must be 16-byte aligned");
-  StencilArgs a{x, ldx, cin_load, (const __bf16*)w_bf16, bias, out, ldc, col_off, cout, residual, ldr, stats, I, D, H, W};
+  SV_REQUIRE(((uintptr_t)x & (act_dtype == SV_BF16 ? 7 : 15)) == 0 && ((uintptr_t)w_bf16 & 15) == 0, "stencil3_fwd: operands must be aligned to 4 elements");
   const int blocks = I * (D / TZ) * (H / TY) * (W / TX);
   hipStream_t s = (hipStream_t)stream;
-  if (groups == 1 && ntiles16 == 1) hipLaunchKernelGGL((stencil3_fwd_kernel<1, 1>), dim3(blocks), dim3(256), 0, s, a);
-  else if (groups == 3 && ntiles16 == 1) hipLaunchKernelGGL((stencil3_fwd_kernel<3, 1>), dim3(blocks), dim3(256), 0, s, a);
-  else if (groups == 1 && ntiles16 == 3) hipLaunchKernelGGL((stencil3_fwd_kernel<1, 3>), dim3(blocks), dim3(256), 0, s, a);
-  else { set_error("stencil3_fwd: unsupported (groups=%d, ntiles16=%d)", groups, ntiles16); return SV_ERR_INVALID; }
+  if (!((groups == 1 && ntiles16 == 1) || (groups == 3 && ntiles16 == 1) || (groups == 1 && ntiles16 == 3))) {
+    set_error("stencil3_fwd: unsupported (groups=%d, ntiles16=%d)", groups, ntiles16);
+    return SV_ERR_INVALID;
+  }
+  SV_DISPATCH_ACT(act_dtype,
+    StencilArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, (const __bf16*)w_bf16, bias, static_cast<AT*>(out), ldc, col_off, cout,
+                       static_cast<const AT*>(residual), ldr, stats, I, D, H, W};
+    if (groups == 1 && ntiles16 == 1) hipLaunchKernelGGL((stencil3_fwd_kernel<1, 1, AT>), dim3(blocks), dim3(256), 0, s, a);
+    else if (groups == 3) hipLaunchKernelGGL((stencil3_fwd_kernel<3, 1, AT>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((stencil3_fwd_kernel<1, 3, AT>), dim3(blocks), dim3(256), 0, s, a););
   return check_launch("sv_stencil3_fwd");
 }
 
-extern "C" int sv_stencil3_wgrad(const float* x, int ldx, int cin_load, int groups, const float* dy, int lddy, int cout_load,
-                                 float* dw, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W, void* stream) {
+extern "C" int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int groups, const void* dy, int lddy, int cout_load,
+                                 float* dw, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W, int act_dtype,
+                                 void* stream) {
   SV_REQUIRE(x && dy && dw, "stencil3_wgrad: null argument");
+  SV_REQUIRE_ACT(act_dtype);
   if (int rc = stencil_check(I, D, H, W)) return rc;
   SV_REQUIRE(cin_load % 4 == 0 && cin_load <= 16 * groups && ldx % 4 == 0 && cout_load % 4 == 0 && cout_load <= 16 && lddy % 4 == 0,
              "stencil3_wgrad: bad channel layout");
   SV_REQUIRE(cout > 0 && cout <= 16 && cin > 0 && c_stride > 0 && c_valid > 0, "stencil3_wgrad: bad channel counts");
-  SV_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "stencil3_wgrad: operands must be 16-byte aligned");
+  SV_REQUIRE((((uintptr_t)x | (uintptr_t)dy) & (act_dtype == SV_BF16 ? 7 : 15)) == 0, "stencil3_wgrad: operands must be aligned to 4 elements");
+  SV_REQUIRE(groups == 1 || groups == 3, "stencil3_wgrad: unsupported groups=%d", groups);
   const int ntiles = I * (D / TZ) * (H / TY) * (W / TX);
-  StencilWArgs a{x, ldx, cin_load, dy, lddy, cout_load, dw, cout, cin, c_stride, c_valid, I, D, H, W, ntiles};
   const int blocks = ntiles < 1024 ? ntiles : 1024;
   hipStream_t s = (hipStream_t)stream;
-  if (groups == 1) hipLaunchKernelGGL((stencil3_wgrad_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
-  else if (groups == 3) hipLaunchKernelGGL((stencil3_wgrad_kernel<3>), dim3(blocks), dim3(256), 0, s, a);
-  else { set_error("stencil3_wgrad: unsupported groups=%d", groups); return SV_ERR_INVALID; }
+  SV_DISPATCH_ACT(act_dtype,
+    StencilWArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, static_cast<const AT*>(dy), lddy, cout_load, dw, cout, cin, c_stride, c_valid, I, D, H, W, ntiles};
+    if (groups == 1) hipLaunchKernelGGL((stencil3_wgrad_kernel<1, AT>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((stencil3_wgrad_kernel<3, AT>), dim3(blocks), dim3(256), 0, s, a););
   return check_launch("sv_stencil3_wgrad");
 }

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libswinvox_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_LRELU = 0, 1, 2, 3
 MATH_F32, MATH_BF16 = 0, 1
+F32, BF16 = 0, 1      # SV_F32 / SV_BF16: storage element of the activation tensors of a call
 
 
 class Geom(C.Structure):
@@ -33,56 +34,78 @@ class Epilogue(C.Structure):
 
 # name -> (restype, argtypes); p = device/host pointer, i = int, l = long long, f = float, u = uint32, z = size_t
 _P, _I, _L, _F, _U = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint32
-_PROTOS = {
-    "sv_version": (_I, []),
-    "sv_conv_gather": (_I, [_P, _P, _P, C.POINTER(Geom), C.POINTER(Epilogue), _I, _P]),
-    "sv_tconv_gather": (_I, [_P, _P, _P, C.POINTER(Geom), C.POINTER(Epilogue), _I, _P]),
-    "sv_conv_wgrad_workspace_floats": (C.c_size_t, [C.POINTER(Geom)]),
-    "sv_conv_wgrad": (_I, [_P, _I, _P, _P, C.POINTER(Geom), _I, _P, _P, _I, _P]),
-    "sv_stencil3_fwd": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
-    "sv_stencil3_wgrad": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "sv_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "sv_colsum": (_I, [_P, _I, _I, _I, _P, _I, _P]),
-    "sv_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
-    "sv_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
-    "sv_ln_image_workspace_floats": (C.c_size_t, [_I, _I]),
-    "sv_ln_image_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U, _P]),
-    "sv_ln_image_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P]),
-    "sv_bn_stats": (_I, [_P, _L, _I, _I, _P, _P]),
-    "sv_bn_finalize": (_I, [_P, _L, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _I, _P]),
-    "sv_scale_shift_act": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _F, _P]),
-    "sv_bn_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _L, _I, _I, _F, _I, _P, _I, _P, _I, _P, _P, _P, _P]),
-    "sv_window_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "sv_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "sv_cross_view_attention_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "sv_cross_view_attention_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "sv_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _L, _P]),
-    "sv_add_n": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P]),
-    "sv_axpby": (_I, [_P, _P, _P, _F, _F, _L, _P]),
-    "sv_relu_bwd": (_I, [_P, _P, _P, _L, _P]),
-    "sv_maxpool2d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "sv_maxpool2d_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "sv_avgpool2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "sv_avgpool2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "sv_decoder_seed_fwd": (_I, [_P, _P, _I, _I, _P]),
-    "sv_decoder_seed_bwd": (_I, [_P, _P, _I, _I, _P]),
-    "sv_maxpool3d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "sv_maxpool3d_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "sv_dropout": (_I, [_P, _P, _L, _F, _U, _P]),
-    "sv_droppath_scale": (_I, [_P, _I, _F, _U, _P]),
-    "sv_rowscale": (_I, [_P, _P, _P, _L, _I, _I, _P]),
-    "sv_dwconv2x2_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
-    "sv_dwconv2x2_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
-    "sv_upsample3to7_add_fwd": (_I, [_P, _P, _I, _P, _I, _I, _P]),
-    "sv_upsample3to7_bwd": (_I, [_P, _P, _I, _I, _P]),
-    "sv_decoder_head_fwd": (_I, [_P, _P, _P, _P, _P, _L, _P]),
-    "sv_decoder_head_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P]),
-    "sv_merge_views_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "sv_merge_views_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "sv_mean_views": (_I, [_P, _P, _I, _I, _I, _P]),
-    "sv_bce_logits": (_I, [_P, _P, _L, _P, _P, _P, _P]),
-    "sv_iou_counts": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+# Entry points whose activation tensors are void* + `int act_dtype` (inserted by call() right before the stream argument)
+_ACT_TYPED = {
+    "sv_conv_gather", "sv_tconv_gather", "sv_conv_wgrad", "sv_stencil3_fwd", "sv_stencil3_wgrad", "sv_colsum",
+    "sv_layernorm_fwd", "sv_layernorm_bwd", "sv_ln_image_fwd", "sv_ln_image_bwd", "sv_bn_stats", "sv_scale_shift_act", "sv_bn_bwd",
+    "sv_window_attention_fwd", "sv_window_attention_bwd", "sv_cross_view_attention_fwd", "sv_cross_view_attention_bwd",
+    "sv_transpose", "sv_add_n", "sv_axpby", "sv_relu_bwd", "sv_maxpool2d_fwd", "sv_maxpool2d_bwd", "sv_avgpool2_fwd", "sv_avgpool2_bwd",
+    "sv_decoder_seed_fwd", "sv_decoder_seed_bwd", "sv_maxpool3d_fwd", "sv_maxpool3d_bwd", "sv_dropout", "sv_rowscale",
+    "sv_dwconv2x2_fwd", "sv_dwconv2x2_bwd", "sv_upsample3to7_add_fwd", "sv_upsample3to7_bwd", "sv_decoder_head_fwd", "sv_decoder_head_bwd",
+    "sv_merge_views_fwd", "sv_merge_views_bwd",
 }
+# argument lists WITHOUT the act_dtype / stream tail (added in load())
+_PROTOS = {
+    "sv_version": (_I, None),
+    "sv_conv_gather": (_I, [_P, _P, _P, C.POINTER(Geom), C.POINTER(Epilogue), _I]),
+    "sv_tconv_gather": (_I, [_P, _P, _P, C.POINTER(Geom), C.POINTER(Epilogue), _I]),
+    "sv_conv_wgrad_workspace_floats": (C.c_size_t, None, [C.POINTER(Geom)]),
+    "sv_conv_wgrad": (_I, [_P, _I, _P, _P, C.POINTER(Geom), _I, _P, _P, _I]),
+    "sv_stencil3_fwd": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I]),
+    "sv_stencil3_wgrad": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "sv_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I]),
+    "sv_colsum": (_I, [_P, _I, _I, _I, _P, _I]),
+    "sv_cast": (_I, [_P, _I, _P, _I, _L]),
+    "sv_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _I]),
+    "sv_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I]),
+    "sv_ln_image_workspace_floats": (C.c_size_t, None, [_I, _I]),
+    "sv_ln_image_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U]),
+    "sv_ln_image_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U]),
+    "sv_bn_stats": (_I, [_P, _L, _I, _I, _P]),
+    "sv_bn_finalize": (_I, [_P, _L, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _I]),
+    "sv_scale_shift_act": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _F]),
+    "sv_bn_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _L, _I, _I, _F, _I, _P, _I, _P, _I, _P, _P, _P]),
+    "sv_window_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
+    "sv_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
+    "sv_cross_view_attention_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I]),
+    "sv_cross_view_attention_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
+    "sv_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _L]),
+    "sv_add_n": (_I, [_P, _P, _P, _P, _P, _L, _I, _I]),
+    "sv_axpby": (_I, [_P, _P, _P, _F, _F, _L]),
+    "sv_relu_bwd": (_I, [_P, _P, _P, _L]),
+    "sv_maxpool2d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I]),
+    "sv_maxpool2d_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I]),
+    "sv_avgpool2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I]),
+    "sv_avgpool2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I]),
+    "sv_decoder_seed_fwd": (_I, [_P, _P, _I, _I]),
+    "sv_decoder_seed_bwd": (_I, [_P, _P, _I, _I]),
+    "sv_maxpool3d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
+    "sv_maxpool3d_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
+    "sv_dropout": (_I, [_P, _P, _L, _F, _U]),
+    "sv_droppath_scale": (_I, [_P, _I, _F, _U]),
+    "sv_rowscale": (_I, [_P, _P, _P, _L, _I, _I]),
+    "sv_dwconv2x2_fwd": (_I, [_P, _P, _P, _P, _I, _I]),
+    "sv_dwconv2x2_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I]),
+    "sv_upsample3to7_add_fwd": (_I, [_P, _P, _I, _P, _I, _I]),
+    "sv_upsample3to7_bwd": (_I, [_P, _P, _I, _I]),
+    "sv_decoder_head_fwd": (_I, [_P, _P, _P, _P, _P, _L]),
+    "sv_decoder_head_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L]),
+    "sv_merge_views_fwd": (_I, [_P, _P, _P, _I, _I, _I]),
+    "sv_merge_views_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I]),
+    "sv_mean_views": (_I, [_P, _P, _I, _I, _I]),
+    "sv_bce_logits": (_I, [_P, _P, _L, _P, _P, _P]),
+    "sv_iou_counts": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+}
+
+
+def _argtypes(name):
+    """Full ctypes argument list of an entry point: listed arguments (+ act_dtype) + stream; helper queries have neither."""
+    spec = _PROTOS[name]
+    if spec[1] is None:
+        return list(spec[2]) if len(spec) > 2 else []
+    return list(spec[1]) + ([_I] if name in _ACT_TYPED else []) + [_P]
+
+
 EXPORTED_SYMBOLS = sorted(list(_PROTOS.keys()) + ["sv_last_error"])
 
 _lib = None
@@ -101,9 +124,9 @@ def load() -> C.CDLL:
                     f"swinvox_amd: {LIB_PATH} is missing - the HIP kernels are the product and there is no fallback. "
                     "Build with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950).")
             lib = C.CDLL(LIB_PATH)
-            for name, (res, args) in _PROTOS.items():
+            for name, spec in _PROTOS.items():
                 fn = getattr(lib, name)
-                fn.restype, fn.argtypes = res, args
+                fn.restype, fn.argtypes = spec[0], _argtypes(name)
             lib.sv_last_error.restype = C.c_char_p
             lib.sv_last_error.argtypes = []
             _lib = lib
@@ -161,11 +184,15 @@ class Tracer:
 
 
 TRACE = None   # set to a Tracer by bench.py
+ACT = F32      # storage dtype code appended to act-typed calls (ops.storage() scopes set it)
 
 
-def call(name: str, *args) -> None:
-    """Invoke an entry point on the current torch stream; a non-zero return becomes a RuntimeError."""
+def call(name: str, *args, act=None) -> None:
+    """Invoke an entry point on the current torch stream; a non-zero return becomes a RuntimeError.  Entry points with
+    activation tensors get the current storage dtype code (hip.ACT, or `act` when the caller overrides it)."""
     lib = load()
+    if name in _ACT_TYPED:
+        args = args + (ACT if act is None else act,)
     tr = TRACE
     if tr is not None and tr._open is None and name in tr.names:   # untimed-by-caller entry point selected for tracing
         tr.begin(name)

@@ -47,6 +47,7 @@ class _ModuleFn(torch.autograd.Function):
         inputs = args[:n_in]
         outs, tape = mod._fwd(*inputs, save=save)
         ctx.mod, ctx.tape, ctx.n_in = mod, tape, n_in
+        ctx.store = ops.get_storage()
         ctx.in_needs = [isinstance(a, torch.Tensor) and a.requires_grad for a in inputs]
         return outs
 
@@ -56,6 +57,8 @@ class _ModuleFn(torch.autograd.Function):
         if ctx.tape is None:
             raise RuntimeError("swinvox_amd: backward requested but the forward ran without a tape (no_grad?)")
         grads = GradStore(mod._param_list())
+        if ops.get_storage() != ctx.store:
+            raise RuntimeError("swinvox_amd: set_storage() changed between forward and backward")
         d_inputs = mod._bwd(ctx.tape, grads, ctx.in_needs, *douts)
         ctx.tape = None
         return (None, None, None) + tuple(d_inputs) + grads.as_tuple()
@@ -78,7 +81,8 @@ class HipModule(nn.Module):
                 raise RuntimeError(f"swinvox_amd: expected float32 inputs, got {t.dtype}")
         params = self._param_list()
         save = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or any(t.requires_grad for t in inputs))
-        return _ModuleFn.apply(self, len(inputs), save, *[t.contiguous() for t in inputs], *params)
+        # module inputs / outputs are fp32; _fwd / _bwd convert to and from the activation storage dtype (ops.to_store / to_f32)
+        return _ModuleFn.apply(self, len(inputs), save, *inputs, *params)
 
     def _seed(self) -> int:
         return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())

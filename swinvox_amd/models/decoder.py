@@ -28,12 +28,12 @@ def as_channels_last12(t: torch.Tensor) -> torch.Tensor:
     B, V = t.shape[:2]
     S = VOX
     want = (V * S * 12, S * 12, 1, 1024 * 12, 32 * 12, 12)
-    if t.is_cuda and t.dtype == torch.float32 and tuple(t.stride()) == want and t.storage_offset() % 4 == 0:
+    if t.is_cuda and tuple(t.stride()) == want and t.storage_offset() % 4 == 0:
         base = t.as_strided((B * V * S, 12), (12, 1), t.storage_offset())
         return base
     ops.hip.check_cuda(t)
     src = t.contiguous()
-    dst = zeros(B * V * S, 12, like=src)
+    dst = torch.zeros(B * V * S, 12, dtype=src.dtype, device=src.device)
     ops.transpose(src, dst, B * V, 9, S, lds=S, ldd=12, sb=9 * S, db=S * 12)   # [i][c][s] -> [i][s][c]
     return dst
 
@@ -62,8 +62,9 @@ class Decoder(HipModule):
     def _fwd(self, feats, save):
         B, V = feats.shape[:2]
         I = B * V
+        feats = ops.to_store(feats)
         f = empty(I * 49, 256, like=feats)
-        ops.transpose(feats.contiguous(), f, I, 256, 49)                    # NCHW -> NHWC
+        ops.transpose(feats, f, I, 256, 49)                    # NCHW -> NHWC
         seed = empty(I * 8, 256, like=f)
         call("sv_decoder_seed_fwd", ptr(f), ptr(seed), I, 256)
         x, g, ctxs = seed, (2, 2, 2), []
@@ -76,13 +77,13 @@ class Decoder(HipModule):
         w5 = self.layer5[0]
         call("sv_decoder_head_fwd", ptr(x), ptr(w5.weight), ptr(w5.bias), ptr(raw12), ptr(vol), I * VOX)
         tape = (B, V, ctxs, x) if save else None
-        return (raw_view(raw12, B, V), vol), tape
+        return (raw_view(ops.to_f32(raw12), B, V), ops.to_f32(vol)), tape
 
     def _bwd(self, tape, grads, in_needs, draw, dvol):
         B, V, ctxs, x8 = tape
         I = B * V
-        draw12 = as_channels_last12(draw) if draw is not None else zeros(I * VOX, 12, like=x8)
-        dvol = dvol.contiguous() if dvol is not None else None
+        draw12 = ops.to_store(as_channels_last12(draw)) if draw is not None else zeros(I * VOX, 12, like=x8)
+        dvol = ops.to_store(dvol) if dvol is not None else None
         w5 = self.layer5[0]
         dx = empty(I * VOX, 8, like=x8)
         call("sv_decoder_head_bwd", ptr(draw12), ptr(dvol), ptr(x8), ptr(w5.weight), ptr(dx), ptr(grads[w5.weight]),
@@ -97,4 +98,4 @@ class Decoder(HipModule):
         call("sv_decoder_seed_bwd", ptr(dx), ptr(df), I, 256)
         dfeat = empty(B, V, 256, 7, 7, like=x8)
         ops.transpose(df, dfeat, I, 49, 256)
-        return (dfeat,)
+        return (ops.to_f32(dfeat),)

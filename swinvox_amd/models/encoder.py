@@ -115,7 +115,7 @@ class Encoder(HipModule):
     def _fwd(self, images, save):
         B, V = images.shape[:2]
         I = B * V
-        images = images.contiguous()
+        images = ops.to_store(images)                                      # fp32 module input -> storage dtype
         tr, sto = self.training, self.stochastic
         seeds = self._seed
         multi = self.cfg.NETWORK.USE_SWIN_T_MULTI_STAGE
@@ -176,14 +176,15 @@ class Encoder(HipModule):
         out = empty(B, V, 256, 7, 7, like=x)
         ops.transpose(y, out, I, 49, 256)                                  # [I][49][256] -> [I][256][49]
         tape = (B, V, c_stem, mp_idx, c_blocks, res_feat, rr, swin_tape, neck, c_cva, c_post) if save else None
-        return out, tape
+        return ops.to_f32(out), tape
 
     def _bwd(self, tape, grads, in_needs, dout):
         B, V, c_stem, mp_idx, c_blocks, res_feat, rr, swin_tape, neck, c_cva, c_post = tape
         I = B * V
         multi = self.cfg.NETWORK.USE_SWIN_T_MULTI_STAGE
+        dout = ops.to_store(dout)
         dy = empty(I * 49, 256, like=dout)
-        ops.transpose(dout.contiguous(), dy, I, 256, 49)                   # [I][256][49] -> [I][49][256]
+        ops.transpose(dout, dy, I, 256, 49)                   # [I][256][49] -> [I][49][256]
         for cba, c in zip(reversed(self._post), reversed(c_post)):
             dy = cba.backward(c, dy, 256, grads)
         dcat = dy                                                          # [I*49, 512]
@@ -225,7 +226,7 @@ class Encoder(HipModule):
         self._s_rr.dgrad(drr, I * 196, (1, 1, 1), self._s_rr.pack_dgrad(self.resnet_reduce.weight), d)
         for blk, c in reversed(c_blocks):
             d = blk.bwd(c, d, grads)
-        dmp = zeros(I * 112 * 112, 64, like=dout)
+        dmp = empty(I * 112 * 112, 64, like=dout)                            # the gather-form max-pool backward writes every element
         call("sv_maxpool2d_bwd", ptr(d), ptr(mp_idx), ptr(dmp), I, 112, 112, 64)
         self._stem.backward(c_stem, dmp, 64, grads, need_dx=False)
         return (None,)

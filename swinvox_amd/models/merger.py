@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..ops import ACT_LRELU, BatchNormState, ConvSpec, call, empty, ptr, zeros
+from ..ops import ACT_LRELU, BatchNormState, ConvSpec, call, empty, fzeros, ptr, zeros
 from ._base import HipModule
 from .decoder import VOX, as_channels_last12, raw_view
 
@@ -52,7 +52,7 @@ class Merger(HipModule):
 
     def _w5_padded(self):
         w5 = self.layer5[0].weight                       # [9,36,3,3,3] -> [9,48,27] with the concat column map
-        wp = zeros(9, 48, 27, like=w5)
+        wp = fzeros(9, 48, 27, like=w5)
         wp[:, self._cat_cols] = w5.detach().reshape(9, 36, 27)
         return wp
 
@@ -64,10 +64,10 @@ class Merger(HipModule):
         cols = self._cat_cols if li == 4 else torch.arange(9, device=w.device)
         wv = w.reshape(cout, cin, 27)
         if not dgrad:
-            wp = zeros(16, 27, 48 if li == 4 else 16, like=w)
+            wp = fzeros(16, 27, 48 if li == 4 else 16, like=w)
             wp[:cout, :, cols] = wv.permute(0, 2, 1)
         else:
-            wp = zeros(48 if li == 4 else 16, 27, 16, like=w)
+            wp = fzeros(48 if li == 4 else 16, 27, 16, like=w)
             wp[cols, :, :cout] = wv.flip(2).permute(1, 2, 0)
         return wp.to(torch.bfloat16).contiguous()
 
@@ -96,7 +96,7 @@ class Merger(HipModule):
             call("sv_stencil3_wgrad", ptr(x), ldx, 48 if li == 4 else 12, 3 if li == 4 else 1, ptr(dy), lddy, lddy if lddy <= 12 else 12,
                  ptr(grads[conv.weight]), conv.out_channels, conv.in_channels, 12 if li == 4 else 16, 9, I, 32, 32, 32)
         elif li == 4:
-            dw5p = zeros(9, 48, 27, like=dy)
+            dw5p = fzeros(9, 48, 27, like=dy)
             self._s5.wgrad(dy, x, I, G, dw5p, lddy=lddy, ldx=ldx)
             grads[conv.weight].view(9, 36, 27).copy_(dw5p[:, self._cat_cols])
         else:
@@ -106,8 +106,8 @@ class Merger(HipModule):
     def _fwd(self, raw, vol, save):
         B, V = raw.shape[:2]
         M, tr, sl = B * V * VOX, self.training, self._slope
-        x12 = as_channels_last12(raw)
-        vol = vol.contiguous()
+        x12 = ops.to_store(as_channels_last12(raw))
+        vol = ops.to_store(vol)
         cat = zeros(M, 48, like=vol)
         w5p = self._w5_padded() if ops.get_math() != "bf16" else None
         ctx14, xin, ldi = [], x12, 12
@@ -136,12 +136,12 @@ class Merger(HipModule):
         out = empty(B, 32, 32, 32, like=vol)
         call("sv_merge_views_fwd", ptr(wl), ptr(vol), ptr(out), B, V, VOX)
         tape = (B, V, x12, vol, cat, ctx14, w5p, y5, st5, z5, y6, st6, wl, out) if save else None
-        return out, tape
+        return ops.to_f32(out), tape
 
     def _bwd(self, tape, grads, in_needs, dout):
         B, V, x12, vol, cat, ctx14, w5p, y5, st5, z5, y6, st6, wl, out = tape
         M, sl = B * V * VOX, self._slope
-        dout = dout.contiguous()
+        dout = ops.to_store(dout)
         dwl = empty(M, 1, like=vol)
         dvol = empty(B, V, 32, 32, 32, like=vol)
         call("sv_merge_views_bwd", ptr(wl), ptr(vol), ptr(out), ptr(dout), ptr(dwl), ptr(dvol), B, V, VOX)
@@ -176,5 +176,5 @@ class Merger(HipModule):
             else:
                 dx = zeros(M, 12, like=vol)
                 self._conv_dgrad(k, dy, 12, dx, 12, False)
-        draw = raw_view(dx, B, V) if in_needs[0] else None
-        return (draw, dvol if in_needs[1] else None)
+        draw = raw_view(ops.to_f32(dx), B, V) if in_needs[0] else None
+        return (draw, ops.to_f32(dvol) if in_needs[1] else None)

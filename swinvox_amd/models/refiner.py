@@ -37,7 +37,7 @@ class Refiner(HipModule):
 
     def _fwd(self, vol, save):
         B, tr = vol.shape[0], self.training
-        v32 = vol.contiguous()                                             # [B,32,32,32,1] channels-last == planar
+        v32 = ops.to_store(vol)                                            # [B,32,32,32,1] channels-last == planar
         x, g, dctx, skips = v32, (32, 32, 32), [], []
         for cba in self._down:
             z, og, c = cba.forward(x, B, g, tr)                            # conv k4 p2 -> 33/17/9 grid, BN over all of it
@@ -72,11 +72,11 @@ class Refiner(HipModule):
         out = empty(B, 32, 32, 32, like=vol)
         call("sv_axpby", ptr(v32), ptr(t8), ptr(out), 0.5, 0.5, out.numel())
         tape = (B, v32, dctx, flat, h1, h2, r4, c6, u8, r8, c7, u16, r16) if save else None
-        return out, tape
+        return ops.to_f32(out), tape
 
     def _bwd(self, tape, grads, in_needs, dout):
         B, v32, dctx, flat, h1, h2, r4, c6, u8, r8, c7, u16, r16 = tape
-        dout = dout.contiguous()
+        dout = ops.to_store(dout)
         c8 = self.layer8[0]
         dt8 = zeros(B * 32768, 4, like=dout)                                # 1 real column, padded to 4 for 16-byte gathers
         ops.transpose(dout, dt8, 1, 1, B * 32768, lds=B * 32768, ldd=4)     # column 0 <- dout
@@ -121,7 +121,7 @@ class Refiner(HipModule):
             return (None,)
         dvol = empty(B, 32, 32, 32, like=dout)
         call("sv_axpby", ptr(dx), ptr(dout), ptr(dvol), 1.0, 0.5, dvol.numel())
-        return (dvol,)
+        return (ops.to_f32(dvol),)
 
 
 def _relu_mask(dy, y, out):

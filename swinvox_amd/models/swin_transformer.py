@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..ops import ACT_GELU, ACT_NONE, ConvSpec, call, empty, ptr, zeros
+from ..ops import ACT_GELU, ACT_NONE, ConvSpec, call, empty, fempty, fzeros, ptr, zeros
 
 _VARIANTS = {
     "tiny": dict(embed_dim=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24)),
@@ -133,7 +133,7 @@ class SwinTransformer(_Holder):
 # kernel chains
 # ---------------------------------------------------------------------------------------------------
 def _drop_scale(I, p, seed, like):
-    sc = empty(I, like=like)
+    sc = fempty(I, like=like)
     call("sv_droppath_scale", ptr(sc), I, float(p), int(seed))
     return sc
 
@@ -232,12 +232,12 @@ def swin_forward(st: SwinTransformer, img_nhwc, I, training, stochastic, seeds):
             ln = st.layer_norm[head_i]
             Cs, Hs = stage.dim, stage.res
             L = Cs * Hs * Hs
-            wt, bt = empty(L, like=x), empty(L, like=x)
+            wt, bt = fempty(L, like=x), fempty(L, like=x)
             ops.transpose(ln.weight, wt, 1, Cs, Hs * Hs)       # [C,HW] -> [HW,C]
             ops.transpose(ln.bias, bt, 1, Cs, Hs * Hs)
             y = empty(I * Hs * Hs, Cs, like=x)
-            mr = empty(2 * I, like=x)
-            ws = empty(int(hipws(I, L)), like=x)
+            mr = fempty(2 * I, like=x)
+            ws = fempty(int(hipws(I, L)), like=x)
             p = st.dropout.p if (training and stochastic) else 0.0
             seed = seeds() if p > 0 else 0
             call("sv_ln_image_fwd", ptr(x), ptr(wt), ptr(bt), ptr(y), ptr(mr), ptr(ws), I, L, float(ln.eps), float(p), seed)
@@ -265,7 +265,7 @@ def swin_backward(st: SwinTransformer, tape, dfeats, I, grads):
             ln = st.layer_norm[hi]
             Cs, Hs = stage.dim, stage.res
             dxe = empty(I * Hs * Hs, Cs, like=xs)
-            dwt, dbt = zeros(L, like=xs), zeros(L, like=xs)
+            dwt, dbt = fzeros(L, like=xs), fzeros(L, like=xs)
             sums = torch.empty(2 * I, dtype=torch.float64, device=xs.device)
             call("sv_ln_image_bwd", ptr(dfeats[hi]), ptr(xs), ptr(wt), ptr(mr), ptr(dxe), ptr(dwt), ptr(dbt), ptr(sums), I, L, float(p), seed)
             ops.transpose(dwt, grads[ln.weight], 1, Hs * Hs, Cs)   # [HW,C] -> [C,HW]

@@ -2,7 +2,8 @@
 weight-grad calls of the contraction engine, and the normalisation / pooling wrappers.
 
 Everything here only enqueues HIP kernels on the current torch stream; torch is used for buffer
-allocation (caching allocator) and nothing else.  All activations are fp32, channels-last.
+allocation (caching allocator) and nothing else.  Activations are channels-last and live in HBM in the current STORAGE
+dtype (fp32, or bf16 under set_storage("bf16")); parameters, their gradients and all statistics are always fp32.
 """
 from __future__ import annotations
 
@@ -15,25 +16,74 @@ import torch
 from . import hip
 from .hip import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, Epilogue, Geom, call, ptr  # noqa: F401
 
-_STATE = {"math": hip.MATH_F32}
+_STATE = {"math": hip.MATH_F32, "store": torch.float32}
 BN_SLOTS = 16   # SV_BN_SLOTS of include/swinvox_hip.h
 
 
 def set_math(mode: str) -> None:
-    """'f32' = exact fp32 MFMA (parity mode); 'bf16' = bf16 MFMA inputs, fp32 accumulate and I/O."""
+    """'f32' = exact fp32 MFMA (parity mode); 'bf16' = bf16 MFMA inputs, fp32 accumulate.  Switching to 'f32' also
+    switches the activation storage back to fp32 (bf16 storage needs bf16 math)."""
     _STATE["math"] = {"f32": hip.MATH_F32, "fp32": hip.MATH_F32, "bf16": hip.MATH_BF16}[mode]
+    if _STATE["math"] == hip.MATH_F32:
+        set_storage("f32")
 
 
 def get_math() -> str:
     return "bf16" if _STATE["math"] == hip.MATH_BF16 else "f32"
 
 
+def set_storage(mode: str) -> None:
+    """HBM element type of the activations (and activation gradients) INSIDE the four modules: 'f32' or 'bf16'.
+    Module inputs / outputs stay fp32 torch tensors (converted at the boundary); arithmetic, statistics, parameters and
+    parameter gradients stay fp32.  'bf16' halves the activation traffic of the path and requires set_math('bf16')."""
+    dt = {"f32": torch.float32, "fp32": torch.float32, "bf16": torch.bfloat16}[mode]
+    if dt == torch.bfloat16 and _STATE["math"] != hip.MATH_BF16:
+        raise RuntimeError("swinvox_amd: bf16 activation storage requires set_math('bf16')")
+    _STATE["store"] = dt
+    hip.ACT = hip.BF16 if dt == torch.bfloat16 else hip.F32
+
+
+def get_storage() -> str:
+    return "bf16" if _STATE["store"] == torch.bfloat16 else "f32"
+
+
 def empty(*shape, like: torch.Tensor = None, device=None) -> torch.Tensor:
-    return torch.empty(*shape, dtype=torch.float32, device=like.device if like is not None else device)
+    """ACTIVATION buffer (current storage dtype)."""
+    return torch.empty(*shape, dtype=_STATE["store"], device=like.device if like is not None else device)
 
 
 def zeros(*shape, like: torch.Tensor = None, device=None) -> torch.Tensor:
+    """Zero-filled ACTIVATION buffer (current storage dtype)."""
+    return torch.zeros(*shape, dtype=_STATE["store"], device=like.device if like is not None else device)
+
+
+def fempty(*shape, like: torch.Tensor = None, device=None) -> torch.Tensor:
+    """fp32 buffer: weight packs, statistics, workspaces, parameter-shaped scratch."""
+    return torch.empty(*shape, dtype=torch.float32, device=like.device if like is not None else device)
+
+
+def fzeros(*shape, like: torch.Tensor = None, device=None) -> torch.Tensor:
     return torch.zeros(*shape, dtype=torch.float32, device=like.device if like is not None else device)
+
+
+def to_store(t: torch.Tensor) -> torch.Tensor:
+    """fp32 module input -> contiguous activation in the current storage dtype (no-op copy avoided for fp32 storage)."""
+    t = t.contiguous()
+    if t.dtype == _STATE["store"]:
+        return t
+    out = torch.empty(t.shape, dtype=_STATE["store"], device=t.device)
+    call("sv_cast", ptr(t), hip.F32 if t.dtype == torch.float32 else hip.BF16, ptr(out), hip.ACT, t.numel())
+    return out
+
+
+def to_f32(t: torch.Tensor) -> torch.Tensor:
+    """contiguous activation -> fp32 module output."""
+    if t.dtype == torch.float32:
+        return t
+    assert t.is_contiguous()
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    call("sv_cast", ptr(t), hip.BF16, ptr(out), hip.F32, t.numel())
+    return out
 
 
 def _t3(v) -> Tuple[int, int, int]:
@@ -97,14 +147,14 @@ class ConvSpec:
         """[cout][tap][cin_mem] from the native parameter layout ([cout,cin,k..] conv / [cin,cout,k..] tconv)."""
         if not self.transposed and self.taps == 1 and self.cin_mem == self.cin:
             return w  # Linear / 1x1 conv: the native layout already is the packed layout
-        out = empty(self.cout * self.taps * self.cin_mem, like=w)
+        out = fempty(self.cout * self.taps * self.cin_mem, like=w)
         A, B = (self.cin, self.cout) if self.transposed else (self.cout, self.cin)
         call("sv_pack_weight", ptr(w), ptr(out), A, B, self.taps, 1 if self.transposed else 0, self.cin_mem)
         return out
 
     def pack_dgrad(self, w: torch.Tensor) -> torch.Tensor:
         """[cin][tap][cout_mem]."""
-        out = empty(self.cin * self.taps * self.cout_mem, like=w)
+        out = fempty(self.cin * self.taps * self.cout_mem, like=w)
         A, B = (self.cin, self.cout) if self.transposed else (self.cout, self.cin)
         call("sv_pack_weight", ptr(w), ptr(out), A, B, self.taps, 0 if self.transposed else 1, self.cout_mem)
         return out
@@ -125,7 +175,8 @@ class ConvSpec:
             pairs = n * og[0] * og[1] * og[2] * self.taps
         flops = 2.0 * pairs * self.cin * self.cout
         nin, nout = n * in_grid[0] * in_grid[1] * in_grid[2], n * og[0] * og[1] * og[2]
-        nbytes = 4.0 * (nin * self.cin + nout * self.cout + self.taps * self.cin * self.cout)
+        esz = 2.0 if _STATE["store"] == torch.bfloat16 else 4.0
+        nbytes = esz * (nin * self.cin + nout * self.cout) + 4.0 * self.taps * self.cin * self.cout
         tr.begin(name, flops, nbytes)
         call(name, *args)
         tr.end()
@@ -157,14 +208,14 @@ class ConvSpec:
         og = self.out_grid(in_grid)
         if self.transposed:   # anchor = x (cin), gathered = dy (cout)
             g = self._geom(n, og, in_grid, self.cout_mem, self.cin, lddy or self.cout_mem)
-            ws = empty(self.cin * self.taps * self.cout_mem, like=dw) if self.taps > 1 else None
+            ws = fempty(self.cin * self.taps * self.cout_mem, like=dw) if self.taps > 1 else None
             self._traced("sv_conv_wgrad", n, in_grid, ptr(x), ldx or self.cin_mem, ptr(dy), ptr(dw), C.byref(g), self.cout, ptr(ws),
                          None, _STATE["math"])
             if db is not None:
                 colsum(dy, n * og[0] * og[1] * og[2], self.cout, lddy or self.cout_mem, db)
         else:                 # anchor = dy (cout), gathered = x (cin)
             g = self._geom(n, in_grid, og, self.cin_mem, self.cout, ldx or self.cin_mem)
-            ws = empty(self.cout * self.taps * self.cin_mem, like=dw) if self.taps > 1 else None
+            ws = fempty(self.cout * self.taps * self.cin_mem, like=dw) if self.taps > 1 else None
             self._traced("sv_conv_wgrad", n, in_grid, ptr(dy), lddy or self.cout_mem, ptr(x), ptr(dw), C.byref(g), self.cin, ptr(ws),
                          ptr(db), _STATE["math"])
 
@@ -193,8 +244,8 @@ def linear_wgrad(dy, x, rows, spec: ConvSpec, dw, db=None):
 # ---------------------------------------------------------------------------------------------------
 def layernorm_fwd(x, gamma, beta, rows, Cdim, merge_hw=(0, 0), eps=1e-5):
     y = empty(rows, Cdim, like=x)
-    mean = empty(rows, like=x)
-    rstd = empty(rows, like=x)
+    mean = fempty(rows, like=x)
+    rstd = fempty(rows, like=x)
     call("sv_layernorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, Cdim, eps, merge_hw[0], merge_hw[1])
     return y, mean, rstd
 
@@ -211,7 +262,7 @@ class BatchNormState:
         self.bn, self.M, self.training, self.C = bn, M, training, bn.num_features
         dev = bn.weight.device
         self.sums = torch.zeros(BN_SLOTS * 2 * self.C, dtype=torch.float64, device=dev) if training else None   # [slot][2C] doubles
-        buf = empty(4 * self.C, device=dev)
+        buf = fempty(4 * self.C, device=dev)
         self.scale, self.shift, self.mean, self.rstd = buf[:self.C], buf[self.C:2 * self.C], buf[2 * self.C:3 * self.C], buf[3 * self.C:]
 
     def finalize(self):
@@ -232,7 +283,9 @@ class BatchNormState:
 
 
 def transpose(src, dst, batch, R, Cc, lds=None, ldd=None, sb=None, db=None):
-    """dst[b][c][r] = src[b][r][c]"""
+    """dst[b][c][r] = src[b][r][c]; element type taken from the tensors (activations in the storage dtype, parameters fp32)"""
     lds = lds or Cc
     ldd = ldd or R
-    call("sv_transpose", ptr(src), ptr(dst), batch, R, Cc, lds, ldd, sb if sb is not None else R * lds, db if db is not None else Cc * ldd)
+    assert src.dtype == dst.dtype
+    call("sv_transpose", ptr(src), ptr(dst), batch, R, Cc, lds, ldd, sb if sb is not None else R * lds, db if db is not None else Cc * ldd,
+         act=hip.BF16 if src.dtype == torch.bfloat16 else hip.F32)

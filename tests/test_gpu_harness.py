@@ -21,7 +21,8 @@ def _nets(dev, cfg):
     return nets
 
 
-def test_train_steps_reduce_loss_and_eval_iou(dev):
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_train_steps_reduce_loss_and_eval_iou(dev, storage):
     cfg = S.default_cfg()
     cfg.TRAIN.ENCODER_LEARNING_RATE = cfg.TRAIN.DECODER_LEARNING_RATE = 1e-3
     cfg.TRAIN.REFINER_LEARNING_RATE = cfg.TRAIN.MERGER_LEARNING_RATE = 1e-3
@@ -31,6 +32,7 @@ def test_train_steps_reduce_loss_and_eval_iou(dev):
     x = (0.5 * torch.randn(2, 2, 3, 224, 224, generator=g)).to(dev)
     gt = (torch.rand(2, 32, 32, 32, generator=g) < 0.1).float().to(dev)
     S.set_math("bf16")
+    S.set_storage(storage)
     try:
         losses = []
         for _ in range(6):

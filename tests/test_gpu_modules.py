@@ -242,8 +242,10 @@ def test_single_stage_config(dev):
         assert rel(p(x.to(dev)), o(x)) < 1e-3
 
 
-def test_bf16_math(dev, nets):
-    """set_math("bf16") (MFMA bf16 operands, fp32 accumulate; LDS-halo stencils in the merger).
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_bf16_math(dev, nets, storage):
+    """set_math("bf16") (MFMA bf16 operands, fp32 accumulate; LDS-halo stencils in the merger), with fp32 and with bf16
+    activation storage (set_storage).
     Tail modules (well conditioned): forward within 2e-2 of the fp32 oracle on the oracle's own inputs, gradients within
     30 % L1 (train-mode BatchNorm over 4 images amplifies bf16 rounding in the backward).  Encoder: this weight set amplifies bf16 rounding (the CPU oracle under torch.autocast(bfloat16) is itself
     ~40 % off its fp32 result), so the HIP error is bounded by 1.5x that CPU-bf16 deviation; gradients must be finite."""
@@ -269,6 +271,7 @@ def test_bf16_math(dev, nets):
     ref_o = ocp[3](mer_o)
     (bce(mer_o, gt) + bce(ref_o, gt)).backward()
     ops.set_math("bf16")
+    ops.set_storage(storage)
     try:
         f_p = pn[0](x.to(dev))
         f_p.square().mean().backward()
