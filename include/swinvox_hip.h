@@ -78,12 +78,13 @@ typedef struct sv_epilogue {
   int col_off;           /* first output column */
 } sv_epilogue;
 
-/* gather form:  out[o, co] = sum_{tap,ci} in[o*s - p + tap, ci] * w[co, tap, ci]      (conv forward; tconv data-grad; Linear) */
-int sv_conv_gather(const void* in, const float* w_packed, void* out, const sv_geom* g, const sv_epilogue* e,
+/* w_packed: [Co][taps][Ci] produced by sv_pack_weight(s); fp32 with act_dtype = SV_F32, bf16 with act_dtype = SV_BF16.
+ * gather form:  out[o, co] = sum_{tap,ci} in[o*s - p + tap, ci] * w[co, tap, ci]      (conv forward; tconv data-grad; Linear) */
+int sv_conv_gather(const void* in, const void* w_packed, void* out, const sv_geom* g, const sv_epilogue* e,
                    int math, int act_dtype, void* stream);
 /* scatter-as-gather form: out[o, co] = sum_{tap,ci : (o+p-tap)%s==0} in[(o+p-tap)/s, ci] * w[co, tap, ci]
  * (transposed-conv forward; strided-conv data-grad), decomposed per output parity class            */
-int sv_tconv_gather(const void* in, const float* w_packed, void* out, const sv_geom* g, const sv_epilogue* e,
+int sv_tconv_gather(const void* in, const void* w_packed, void* out, const sv_geom* g, const sv_epilogue* e,
                     int math, int act_dtype, void* stream);
 /* weight gradient: dw[ca, cg, tap] += sum_r anchor[r, ca] * gathered[r*s - p + tap, cg]   (fp32 atomics; dw pre-zeroed
  * or holding a running sum).  g->Do.. = anchor grid, g->Di.. = gathered grid, g->Co = anchor channels (row stride lda),
@@ -106,8 +107,18 @@ int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups, const void
 int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int groups, const void* dy, int lddy, int cout_load,
                       float* dw, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W, int act_dtype,
                       void* stream);
-/* dst[a][t][b] (b padded with zeros to bpad) from src[a][b][t]  (swap=0), or dst[b][t][a..apad] (swap=1)   (weights: fp32) */
-int sv_pack_weight(const float* src, float* dst, int A, int B, int T, int swap, int pad_to, void* stream);
+/* dst[a][t][b] (b padded with zeros to pad_to) from the fp32 parameter src[a][b][t] (swap=0), or dst[b][t][a..pad_to] (swap=1);
+ * dst elements are out_dtype (SV_F32 / SV_BF16) */
+int sv_pack_weight(const float* src, void* dst, int A, int B, int T, int swap, int pad_to, int out_dtype, void* stream);
+/* the same for a whole table of weights in ONE launch.  descs_dev: DEVICE array; rows_out / inner_out as derived by
+ * sv_pack_weight (rows_out = swap ? B : A, inner_out = max(pad_to, swap ? A : B)); block0 = exclusive prefix sum of
+ * ceil(rows_out*T*inner_out / sv_pack_weights_block_elems()) over the table, total_blocks = its grand total */
+typedef struct sv_pack_desc {
+  const float* src; void* dst;
+  int A, B, T, swap, rows_out, inner_out, block0, reserved;
+} sv_pack_desc;
+int sv_pack_weights_block_elems(void);
+int sv_pack_weights(const sv_pack_desc* descs_dev, int n, int total_blocks, int out_dtype, void* stream);
 /* per-column sum over rows: out[c] (+)= sum_r x[r*ld + c]  (bias gradients) */
 int sv_colsum(const void* x, int rows, int cols, int ld, float* out, int accumulate, int act_dtype, void* stream);
 /* element-wise storage conversion (module boundaries: nn.Module inputs / outputs are fp32) */

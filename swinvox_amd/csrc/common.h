@@ -44,6 +44,16 @@ template <> struct V4<__bf16> {
   }
 };
 
+// N-element raw vectors (N = 4: 8 or 16 bytes, N = 8: bf16 only, 16 bytes)
+template <typename T, int N> struct VecN;
+template <> struct VecN<float, 4> : V4<float> {};
+template <> struct VecN<__bf16, 4> : V4<__bf16> {};
+template <> struct VecN<__bf16, 8> {
+  typedef bf16x8 type;
+  static __device__ __forceinline__ type zero() { type z; for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f; return z; }
+  static __device__ __forceinline__ type load(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+};
+
 // host-side dispatch on the activation dtype of a call: BODY sees the element type as AT
 #define SV_DISPATCH_ACT(act_dtype, ...)                  \
   do {                                                   \

@@ -37,7 +37,7 @@ struct ClassInfo {  // one output parity class of a transposed gather
   int T[3];         // taps of the class per axis
 };
 struct IGemmArgs {
-  const void* x; const float* w; void* y;   // x, y: activations (AT); w: fp32 packed weights
+  const void* x; const void* w; void* y;   // x, y: activations (AT); w: packed weights (fp32, or bf16 with bf16 activations)
   Geom g; Epi e;
   int Ktot;         // row length of packed weights = taps_total * Ci
   ClassInfo cls[8];
@@ -70,6 +70,11 @@ __device__ __forceinline__ void store4(__bf16* dst, float4 v) {
 __device__ __forceinline__ void store4(__bf16* dst, bf16x4 v) { *reinterpret_cast<bf16x4*>(dst) = v; }   // bf16 storage: no conversion
 __device__ __forceinline__ void store4(float* dst, bf16x4 v) {
   *reinterpret_cast<float4*>(dst) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void store4(__bf16* dst, bf16x8 v) { *reinterpret_cast<bf16x8*>(dst) = v; }   // 16-byte operand chunk
+__device__ __forceinline__ void store4(float* dst, bf16x8 v) {   // never selected (bf16 storage implies bf16 MFMA operands)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dst[i] = (float)v[i];
 }
 
 // ---- MFMA over one K-step slab, operands stored [row][k] (k contiguous) ---------------------------
@@ -176,15 +181,18 @@ __device__ __forceinline__ void decode_row(int m, int c0, int c1, int c2, int& n
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------------
-template <bool BF16, bool TCONV, typename TL, typename AT>
+// AT = activation storage type, WT = packed-weight type, VEC = elements per operand load (4, or 8 = 16 bytes of bf16)
+template <bool BF16, bool TCONV, typename TL, typename AT, typename WT, int VEC>
 __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kernel(const IGemmArgs p) {
   typedef typename Cfg<BF16>::T LT;
-  typedef typename V4<AT>::type AV;
+  typedef typename VecN<AT, VEC>::type AV;
+  typedef typename VecN<WT, VEC>::type WV;
   const AT* __restrict__ X = static_cast<const AT*>(p.x);
+  const WT* __restrict__ Wt = static_cast<const WT*>(p.w);
   AT* __restrict__ Y = static_cast<AT*>(p.y);
   constexpr int BK = Cfg<BF16>::BK, LD = BK + Cfg<BF16>::PAD;
   constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT;
-  constexpr int TPR = BK / 4;          // threads per tile row (one float4 each)
+  constexpr int TPR = BK / VEC;        // threads per tile row (one VEC-element chunk each)
   constexpr int NTHR = TL::NTHR, NW = TL::NW;
   constexpr int RPP = NTHR / TPR;      // rows per pass
   constexpr int NA = BM / RPP;
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
   const int col0 = (tlin % tiles_n) * BN;
 
   // ---- per-thread loader state -----------------------------------------------------------------
-  const int kq = (tid % TPR) * 4;
+  const int kq = (tid % TPR) * VEC;
   const int rb = tid / TPR;
   int a_n[NA], a_d[NA], a_h[NA], a_w[NA];
   bool a_ok[NA];
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
     if constexpr (TCONV) { a_d[i] = ci.ib0[0] + d_; a_h[i] = ci.ib0[1] + h_; a_w[i] = ci.ib0[2] + w_; }   // gathered idx = this - t
     else { a_d[i] = d_ * g.sd - g.pd; a_h[i] = h_ * g.sh - g.ph; a_w[i] = w_ * g.sw - g.pw; }              // gathered idx = this + t
   }
-  const bool vec_ok = (g.Ci & 3) == 0 && (g.ldi & 3) == 0;
+  const bool vec_ok = (g.Ci % VEC) == 0 && (g.ldi % VEC) == 0;
   // running tap state of this thread's k-chunk (vector path): channel offset kc inside the tap, tap coords
   int kc = 0, tw = 0, th = 0, td = 0, kcur = kq;
   if (vec_ok && K > 0) {
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
   }
 
   AV ra[NA];
-  float4 rbv[NB];
+  WV rbv[NB];
   auto load_tile = [&]() {   // loads the tile at the running k position, then advances the state by BK
     if (vec_ok) {
       const bool kok = td < T0;
@@ -259,9 +267,9 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
         const bool ok = kok && a_ok[i] && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi;
         if (ok) {
           const size_t off = ((((size_t)a_n[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + kc;
-          ra[i] = V4<AT>::load(X + off);
+          ra[i] = VecN<AT, VEC>::load(X + off);
         } else {
-          ra[i] = V4<AT>::zero();
+          ra[i] = VecN<AT, VEC>::zero();
         }
       }
       // weights: [Co][taps_total][Ci]; TCONV maps the class-local tap to its kernel index
@@ -275,8 +283,8 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int nl = rb + RPP * i, n = col0 + nl;
-        if (nl < BN && n < g.Co && kok) rbv[i] = *reinterpret_cast<const float4*>(p.w + (size_t)n * p.Ktot + woff);
-        else rbv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nl < BN && n < g.Co && kok) rbv[i] = VecN<WT, VEC>::load(Wt + (size_t)n * p.Ktot + woff);
+        else rbv[i] = VecN<WT, VEC>::zero();
       }
       // advance
       kcur += BK; kc += BK;
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
         kc -= g.Ci;
         if (++tw == T2) { tw = 0; if (++th == T1) { th = 0; ++td; } }
       }
-    } else {  // scalar path: any Ci (stem Ci=3, refiner head Ci=1 ...), per-element tap decode
+    } else if constexpr (VEC == 4) {  // scalar path: any Ci (stem Ci=3, refiner head Ci=1 ...), per-element tap decode
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         float v[4];
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
           const bool ok = kk < K && a_ok[i] && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi;
           v[j] = ok ? ldf(X + ((((size_t)a_n[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + c) : 0.f;
         }
-        ra[i] = V4<AT>::make(v[0], v[1], v[2], v[3]);
+        ra[i] = VecN<AT, 4>::make(v[0], v[1], v[2], v[3]);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -317,11 +325,11 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
               const int kd_ = ci.r[0] + g.sd * td_, kh_ = ci.r[1] + g.sh * th_, kw_ = ci.r[2] + g.sw * tw_;
               kidx = ((kd_ * g.kh + kh_) * g.kw + kw_) * g.Ci + c;
             }
-            val = p.w[(size_t)n * p.Ktot + kidx];
+            val = (float)Wt[(size_t)n * p.Ktot + kidx];
           }
           v[j] = val;
         }
-        rbv[i] = make_float4(v[0], v[1], v[2], v[3]);
+        rbv[i] = VecN<WT, 4>::make(v[0], v[1], v[2], v[3]);
       }
       kcur += BK;
     }
@@ -460,18 +468,18 @@ struct WGradArgs {
   float* dbias;     // optional: dbias[ca] += sum_r anchor[r, ca] (bias gradient), folded into the k_out-tile-0 workgroups
 };
 
-template <bool BF16, typename TL, typename AT>
+template <bool BF16, typename TL, typename AT, int VEC>
 __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void wgrad_kernel(const WGradArgs p) {
   typedef typename Cfg<BF16>::T LT;
-  typedef typename V4<AT>::type AV;
+  typedef typename VecN<AT, VEC>::type AV;
   const AT* __restrict__ ANC = static_cast<const AT*>(p.anchor);
   const AT* __restrict__ GAT = static_cast<const AT*>(p.gathered);
   constexpr int BK = Cfg<BF16>::BK, PAD = Cfg<BF16>::PAD;
   constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT;
   constexpr int LDA = BM + PAD, LDB = BN + PAD;
   constexpr int NTHR = TL::NTHR;
-  constexpr int A4 = BM / 4, A_RPP = NTHR / A4, A_PASS = (BK + A_RPP - 1) / A_RPP;   // float4 columns / rows per pass / passes
-  constexpr int B4 = BN / 4, B_RPP = NTHR / B4, B_PASS = (BK + B_RPP - 1) / B_RPP;
+  constexpr int A4 = BM / VEC, A_RPP = NTHR / A4, A_PASS = (BK + A_RPP - 1) / A_RPP;   // VEC-element columns / rows per pass / passes
+  constexpr int B4 = BN / VEC, B_RPP = NTHR / B4, B_PASS = (BK + B_RPP - 1) / B_RPP;
   __shared__ __attribute__((aligned(16))) LT As[2 * BK * LDA];  // [stage][r][ca]     (double-buffered: one barrier / K step)
   __shared__ __attribute__((aligned(16))) LT Bs[2 * BK * LDB];  // [stage][r][k_out]
 
@@ -488,9 +496,9 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void wgrad_kerne
   if (r_end > p.Mrows) r_end = p.Mrows;
   if (r_begin >= r_end) return;
 
-  const int a_c = (tid % A4) * 4, a_r = tid / A4;
-  const int b_kl = (tid % B4) * 4, b_k = ko0 + b_kl, b_r = tid / B4;
-  const bool avec = (p.lda & 3) == 0, bvec = (g.Ci & 3) == 0 && (g.ldi & 3) == 0;
+  const int a_c = (tid % A4) * VEC, a_r = tid / A4;
+  const int b_kl = (tid % B4) * VEC, b_k = ko0 + b_kl, b_r = tid / B4;
+  const bool avec = (p.lda % VEC) == 0, bvec = (g.Ci % VEC) == 0 && (g.ldi % VEC) == 0;
   const bool dense = (g.Do * g.Ho * g.Wo == 1) && taps == 1;   // Linear: gathered row == anchor row
   int b_c = 0, b_td = 0, b_th = 0, b_tw = 0;
   if (bvec) {
@@ -508,16 +516,16 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void wgrad_kerne
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       const int rl = a_r + A_RPP * i, r = r0 + rl;
-      AV q = V4<AT>::zero();
+      AV q = VecN<AT, VEC>::zero();
       if (rl < BK && r < r_end) {
         const AT* src = ANC + (size_t)r * p.lda + ca0 + a_c;
-        if (avec && ca0 + a_c + 3 < g.Co) {
-          q = V4<AT>::load(src);
-        } else {
+        if (avec && ca0 + a_c + VEC - 1 < g.Co) {
+          q = VecN<AT, VEC>::load(src);
+        } else if constexpr (VEC == 4) {
           float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (ca0 + a_c + j < g.Co) v[j] = ldf(src + j);
-          q = V4<AT>::make(v[0], v[1], v[2], v[3]);
+          q = VecN<AT, 4>::make(v[0], v[1], v[2], v[3]);
         }
       }
       ra[i] = q;
@@ -525,24 +533,24 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void wgrad_kerne
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
       const int rl = b_r + B_RPP * i, r = r0 + rl;
-      AV q = V4<AT>::zero();
+      AV q = VecN<AT, VEC>::zero();
       if (rl < BK && r < r_end) {
         if (dense) {
           if (bvec) {
-            if (b_k < Kout) q = V4<AT>::load(GAT + (size_t)r * g.ldi + b_k);
-          } else {
+            if (b_k < Kout) q = VecN<AT, VEC>::load(GAT + (size_t)r * g.ldi + b_k);
+          } else if constexpr (VEC == 4) {
             float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (b_k + j < Kout) v[j] = ldf(GAT + (size_t)r * g.ldi + b_k + j);
-            q = V4<AT>::make(v[0], v[1], v[2], v[3]);
+            q = VecN<AT, 4>::make(v[0], v[1], v[2], v[3]);
           }
         } else {
           const int bd = bd_[i] * g.sd - g.pd, bh = bh_[i] * g.sh - g.ph, bw = bw_[i] * g.sw - g.pw;
           if (bvec) {
             const int id = bd + b_td, ih = bh + b_th, iw = bw + b_tw;
             if (b_k < Kout && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi)
-              q = V4<AT>::load(GAT + ((((size_t)bn_[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + b_c);
-          } else {
+              q = VecN<AT, VEC>::load(GAT + ((((size_t)bn_[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + b_c);
+          } else if constexpr (VEC == 4) {
             float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -555,7 +563,7 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void wgrad_kerne
                   v[j] = ldf(GAT + ((((size_t)bn_[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + c);
               }
             }
-            q = V4<AT>::make(v[0], v[1], v[2], v[3]);
+            q = VecN<AT, 4>::make(v[0], v[1], v[2], v[3]);
           }
         }
       }
@@ -651,7 +659,8 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ ws, float* __restr
 // ------------------------------------------------------------------------------------------------
 // small helpers: weight repack, column sums
 // ------------------------------------------------------------------------------------------------
-__global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int A, int B, int T, int swap,
+template <typename WT>
+__global__ void pack_weight_kernel(const float* __restrict__ src, WT* __restrict__ dst, int A, int B, int T, int swap,
                                    int rows_out, int inner_out) {
   // dst[rows_out][T][inner_out]; swap=0: rows=A inner=B ; swap=1: rows=B inner=A ; zero beyond the valid range
   const long long total = (long long)rows_out * T * inner_out;
@@ -659,7 +668,32 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
     const int in_ = (int)(i % inner_out); long long t2 = i / inner_out;
     const int t = (int)(t2 % T); const int ro = (int)(t2 / T);
     const int a = swap ? in_ : ro, b = swap ? ro : in_;
-    dst[i] = (a < A && b < B) ? src[((size_t)a * B + b) * T + t] : 0.f;
+    dst[i] = (WT)((a < A && b < B) ? src[((size_t)a * B + b) * T + t] : 0.f);
+  }
+}
+
+// every weight pack of a module in ONE launch: workgroup -> descriptor by binary search over the block prefix; a
+// workgroup produces PACK_PER_BLOCK consecutive output elements of its descriptor
+constexpr int PACK_PER_BLOCK = 2048;
+template <typename WT>
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const sv_pack_desc* __restrict__ descs, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {   // last descriptor with block0 <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const sv_pack_desc d = descs[lo];
+  const float* __restrict__ src = d.src;
+  WT* __restrict__ dst = static_cast<WT*>(d.dst);
+  const long long total = (long long)d.rows_out * d.T * d.inner_out;
+  const long long i0 = (long long)(blockIdx.x - d.block0) * PACK_PER_BLOCK;
+  for (int k = threadIdx.x; k < PACK_PER_BLOCK; k += 256) {
+    const long long i = i0 + k;
+    if (i >= total) break;
+    const int in_ = (int)(i % d.inner_out); long long t2 = i / d.inner_out;
+    const int t = (int)(t2 % d.T); const int ro = (int)(t2 / d.T);
+    const int a = d.swap ? in_ : ro, b = d.swap ? ro : in_;
+    dst[i] = (WT)((a < d.A && b < d.B) ? src[((size_t)a * d.B + b) * d.T + t] : 0.f);
   }
 }
 
@@ -710,11 +744,14 @@ template <bool TCONV>
 static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, int act, hipStream_t s) {
   const int Co = a.g.Co;
   const bool bf = math == SV_MATH_BF16;
-#define SV_LAUNCH_IG(TL)                                                                                              \
-  do {                                                                                                                \
-    if (!bf) hipLaunchKernelGGL((igemm_kernel<false, TCONV, TL, float>), grid, dim3(TL::NTHR), 0, s, a);               \
-    else if (act == SV_BF16) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TL, __bf16>), grid, dim3(TL::NTHR), 0, s, a); \
-    else hipLaunchKernelGGL((igemm_kernel<true, TCONV, TL, float>), grid, dim3(TL::NTHR), 0, s, a);                    \
+  // bf16 storage: weights are bf16 too; 16-byte operand chunks when the gathered rows allow it
+  const bool v8 = act == SV_BF16 && (a.g.Ci % 8) == 0 && (a.g.ldi % 8) == 0 && ((uintptr_t)a.x & 15) == 0;
+#define SV_LAUNCH_IG(TL)                                                                                                           \
+  do {                                                                                                                             \
+    if (!bf) hipLaunchKernelGGL((igemm_kernel<false, TCONV, TL, float, float, 4>), grid, dim3(TL::NTHR), 0, s, a);                  \
+    else if (act != SV_BF16) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TL, float, float, 4>), grid, dim3(TL::NTHR), 0, s, a);   \
+    else if (v8) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TL, __bf16, __bf16, 8>), grid, dim3(TL::NTHR), 0, s, a);            \
+    else hipLaunchKernelGGL((igemm_kernel<true, TCONV, TL, __bf16, __bf16, 4>), grid, dim3(TL::NTHR), 0, s, a);                    \
   } while (0)
   if (Co <= 16) {
     dim3 grid(cdiv(M, TileNarrow::BM) * cdiv(Co, TileNarrow::BN), ncls);
@@ -737,7 +774,7 @@ typedef Tile<2, 4, 4, 2> WTileWide;      // 128 x 128, 8 waves
 
 using namespace sv;
 
-extern "C" int sv_conv_gather(const void* in, const float* w, void* out, const sv_geom* g, const sv_epilogue* e,
+extern "C" int sv_conv_gather(const void* in, const void* w, void* out, const sv_geom* g, const sv_epilogue* e,
                               int math, int act_dtype, void* stream) {
   if (int rc = check_common(g, e, in, w, out, act_dtype)) return rc;
   SV_REQUIRE_ACT(act_dtype);
@@ -750,7 +787,7 @@ extern "C" int sv_conv_gather(const void* in, const float* w, void* out, const s
   return check_launch("sv_conv_gather");
 }
 
-extern "C" int sv_tconv_gather(const void* in, const float* w, void* out, const sv_geom* g, const sv_epilogue* e,
+extern "C" int sv_tconv_gather(const void* in, const void* w, void* out, const sv_geom* g, const sv_epilogue* e,
                                int math, int act_dtype, void* stream) {
   if (int rc = check_common(g, e, in, w, out, act_dtype)) return rc;
   SV_REQUIRE_ACT(act_dtype);
@@ -830,11 +867,16 @@ extern "C" int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, 
   a.rows_per_split = (int)rps;
   dim3 grid((unsigned)(cdiv(g->Co, BMw) * cdiv(Kout, BNw) * splits));
   const bool bf = math == SV_MATH_BF16;
-#define SV_LAUNCH_WG(TL)                                                                                         \
-  do {                                                                                                           \
-    if (!bf) hipLaunchKernelGGL((wgrad_kernel<false, TL, float>), grid, dim3(TL::NTHR), 0, s, a);                 \
-    else if (act == SV_BF16) hipLaunchKernelGGL((wgrad_kernel<true, TL, __bf16>), grid, dim3(TL::NTHR), 0, s, a); \
-    else hipLaunchKernelGGL((wgrad_kernel<true, TL, float>), grid, dim3(TL::NTHR), 0, s, a);                      \
+  // 16-byte operand chunks with bf16 storage when every row start and channel count allows it (Co % 8 keeps the edge
+  // chunk of the anchor whole; otherwise the 4-element variant with its scalar edge path is used)
+  const bool v8 = act == SV_BF16 && (lda % 8) == 0 && (g->Co % 8) == 0 && (g->Ci % 8) == 0 && (g->ldi % 8) == 0 &&
+                  (((uintptr_t)anchor | (uintptr_t)gathered) & 15) == 0;
+#define SV_LAUNCH_WG(TL)                                                                                               \
+  do {                                                                                                                 \
+    if (!bf) hipLaunchKernelGGL((wgrad_kernel<false, TL, float, 4>), grid, dim3(TL::NTHR), 0, s, a);                    \
+    else if (act != SV_BF16) hipLaunchKernelGGL((wgrad_kernel<true, TL, float, 4>), grid, dim3(TL::NTHR), 0, s, a);     \
+    else if (v8) hipLaunchKernelGGL((wgrad_kernel<true, TL, __bf16, 8>), grid, dim3(TL::NTHR), 0, s, a);               \
+    else hipLaunchKernelGGL((wgrad_kernel<true, TL, __bf16, 4>), grid, dim3(TL::NTHR), 0, s, a);                       \
   } while (0)
   if (narrow) SV_LAUNCH_WG(WTileNarrow);
   else if (wide) SV_LAUNCH_WG(WTileWide);
@@ -848,15 +890,29 @@ extern "C" int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, 
   return check_launch("sv_conv_wgrad");
 }
 
-extern "C" int sv_pack_weight(const float* src, float* dst, int A, int B, int T, int swap, int pad_to, void* stream) {
+extern "C" int sv_pack_weight(const float* src, void* dst, int A, int B, int T, int swap, int pad_to, int out_dtype, void* stream) {
   SV_REQUIRE(src && dst && A > 0 && B > 0 && T > 0, "pack_weight: bad arguments");
+  SV_REQUIRE_ACT(out_dtype);
   const int rows_out = swap ? B : A;
   int inner = swap ? A : B;
   if (pad_to > inner) inner = pad_to;
   const long long total = (long long)rows_out * T * inner;
   int blocks = cdiv(total, 256); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, A, B, T, swap, rows_out, inner);
+  if (out_dtype == SV_BF16)
+    hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, static_cast<__bf16*>(dst), A, B, T, swap, rows_out, inner);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, static_cast<float*>(dst), A, B, T, swap, rows_out, inner);
   return check_launch("sv_pack_weight");
+}
+
+extern "C" int sv_pack_weights_block_elems(void) { return PACK_PER_BLOCK; }
+
+extern "C" int sv_pack_weights(const sv_pack_desc* descs_dev, int n, int total_blocks, int out_dtype, void* stream) {
+  SV_REQUIRE(descs_dev && n > 0 && total_blocks > 0, "pack_weights: bad arguments");
+  SV_REQUIRE_ACT(out_dtype);
+  if (out_dtype == SV_BF16) hipLaunchKernelGGL(pack_weights_batched_kernel<__bf16>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+  else hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+  return check_launch("sv_pack_weights");
 }
 
 extern "C" int sv_colsum(const void* x, int rows, int cols, int ld, float* out, int accumulate, int act_dtype, void* stream) {

@@ -32,6 +32,11 @@ class Epilogue(C.Structure):
                 ("col_off", C.c_int)]
 
 
+class PackDesc(C.Structure):   # sv_pack_desc
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("A", C.c_int), ("B", C.c_int), ("T", C.c_int), ("swap", C.c_int),
+                ("rows_out", C.c_int), ("inner_out", C.c_int), ("block0", C.c_int), ("reserved", C.c_int)]
+
+
 # name -> (restype, argtypes); p = device/host pointer, i = int, l = long long, f = float, u = uint32, z = size_t
 _P, _I, _L, _F, _U = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint32
 # Entry points whose activation tensors are void* + `int act_dtype` (inserted by call() right before the stream argument)
@@ -53,7 +58,9 @@ _PROTOS = {
     "sv_conv_wgrad": (_I, [_P, _I, _P, _P, C.POINTER(Geom), _I, _P, _P, _I]),
     "sv_stencil3_fwd": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I]),
     "sv_stencil3_wgrad": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
-    "sv_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I]),
+    "sv_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I]),
+    "sv_pack_weights_block_elems": (_I, None),
+    "sv_pack_weights": (_I, [_P, _I, _I, _I]),
     "sv_colsum": (_I, [_P, _I, _I, _I, _P, _I]),
     "sv_cast": (_I, [_P, _I, _P, _I, _L]),
     "sv_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _I]),

@@ -45,7 +45,13 @@ class _ModuleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, n_in, save, *args):
         inputs = args[:n_in]
-        outs, tape = mod._fwd(*inputs, save=save)
+        packs = mod.__dict__.setdefault("_packs", ops.PackCache())
+        ops.set_pack_cache(packs)
+        try:
+            packs.refresh()                      # every registered weight pack of the module in one launch
+            outs, tape = mod._fwd(*inputs, save=save)
+        finally:
+            ops.set_pack_cache(None)
         ctx.mod, ctx.tape, ctx.n_in = mod, tape, n_in
         ctx.store = ops.get_storage()
         ctx.in_needs = [isinstance(a, torch.Tensor) and a.requires_grad for a in inputs]
@@ -59,7 +65,11 @@ class _ModuleFn(torch.autograd.Function):
         grads = GradStore(mod._param_list())
         if ops.get_storage() != ctx.store:
             raise RuntimeError("swinvox_amd: set_storage() changed between forward and backward")
-        d_inputs = mod._bwd(ctx.tape, grads, ctx.in_needs, *douts)
+        ops.set_pack_cache(mod.__dict__.setdefault("_packs", ops.PackCache()))
+        try:
+            d_inputs = mod._bwd(ctx.tape, grads, ctx.in_needs, *douts)
+        finally:
+            ops.set_pack_cache(None)
         ctx.tape = None
         return (None, None, None) + tuple(d_inputs) + grads.as_tuple()
 

@@ -142,22 +142,32 @@ class ConvSpec:
             return tuple((g[i] - 1) * self.s[i] - 2 * self.p[i] + self.k[i] for i in range(3))
         return tuple((g[i] + 2 * self.p[i] - self.k[i]) // self.s[i] + 1 for i in range(3))
 
-    # ---- weight packs (device copies made once per step) -------------------------------------------
-    def pack_fwd(self, w: torch.Tensor) -> torch.Tensor:
-        """[cout][tap][cin_mem] from the native parameter layout ([cout,cin,k..] conv / [cin,cout,k..] tconv)."""
-        if not self.transposed and self.taps == 1 and self.cin_mem == self.cin:
-            return w  # Linear / 1x1 conv: the native layout already is the packed layout
-        out = fempty(self.cout * self.taps * self.cin_mem, like=w)
+    # ---- weight packs (device copies made once per step; element type = the activation storage dtype) --------
+    def pack_args(self, kind: str):
+        """(A, B, T, swap, pad_to, rows_out, inner_out) of sv_pack_weight for the forward ('f': [cout][tap][cin_mem]) or the
+        data-gradient ('d': [cin][tap][cout_mem]) pack of the native parameter ([cout,cin,k..] conv / [cin,cout,k..] tconv)."""
         A, B = (self.cin, self.cout) if self.transposed else (self.cout, self.cin)
-        call("sv_pack_weight", ptr(w), ptr(out), A, B, self.taps, 1 if self.transposed else 0, self.cin_mem)
-        return out
+        if kind == "f":
+            swap, pad = (1 if self.transposed else 0), self.cin_mem
+        else:
+            swap, pad = (0 if self.transposed else 1), self.cout_mem
+        rows, inner = (B, max(A, pad)) if swap else (A, max(B, pad))
+        return A, B, self.taps, swap, pad, rows, inner
+
+    def _pack(self, w: torch.Tensor, kind: str) -> torch.Tensor:
+        dt = _STATE["store"]
+        if kind == "f" and dt == torch.float32 and not self.transposed and self.taps == 1 and self.cin_mem == self.cin:
+            return w  # Linear / 1x1 conv in fp32: the native layout already is the packed layout
+        cache = _STATE.get("packs")
+        if cache is not None:
+            return cache.get(self, w, kind)
+        return pack_one(self, w, kind)
+
+    def pack_fwd(self, w: torch.Tensor) -> torch.Tensor:
+        return self._pack(w, "f")
 
     def pack_dgrad(self, w: torch.Tensor) -> torch.Tensor:
-        """[cin][tap][cout_mem]."""
-        out = fempty(self.cin * self.taps * self.cout_mem, like=w)
-        A, B = (self.cin, self.cout) if self.transposed else (self.cout, self.cin)
-        call("sv_pack_weight", ptr(w), ptr(out), A, B, self.taps, 0 if self.transposed else 1, self.cout_mem)
-        return out
+        return self._pack(w, "d")
 
     def _geom(self, n, gathered_grid, produced_grid, ci, co, ldi) -> Geom:
         return Geom(n, *gathered_grid, *produced_grid, ci, co, *self.k, *self.s, *self.p, ldi)
@@ -184,6 +194,8 @@ class ConvSpec:
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x, n, in_grid, w_packed, out, *, ldi=None, ldc=None, **epi):
         og = self.out_grid(in_grid)
+        if isinstance(w_packed, torch.nn.Parameter) or w_packed.dtype != _STATE["store"]:
+            w_packed = self.pack_fwd(w_packed)     # raw parameter: pack / convert (identity for a Linear in fp32 storage)
         g = self._geom(n, in_grid, og, self.cin_mem, self.cout, ldi or self.cin_mem)
         e = _epilogue(ldc or self.cout, **epi)
         self._traced("sv_tconv_gather" if self.transposed else "sv_conv_gather", n, in_grid, ptr(x), ptr(w_packed), ptr(out),
@@ -218,6 +230,76 @@ class ConvSpec:
             ws = fempty(self.cout * self.taps * self.cin_mem, like=dw) if self.taps > 1 else None
             self._traced("sv_conv_wgrad", n, in_grid, ptr(dy), lddy or self.cout_mem, ptr(x), ptr(dw), C.byref(g), self.cin, ptr(ws),
                          ptr(db), _STATE["math"])
+
+
+def pack_one(spec: "ConvSpec", w: torch.Tensor, kind: str) -> torch.Tensor:
+    """One weight pack with its own launch (first step of a module, tests)."""
+    A, B, T, swap, pad, rows, inner = spec.pack_args(kind)
+    out = torch.empty(rows * T * inner, dtype=_STATE["store"], device=w.device)
+    call("sv_pack_weight", ptr(w), ptr(out), A, B, T, swap, pad, hip.ACT)
+    return out
+
+
+class PackCache:
+    """All weight packs of one module from ONE batched launch per forward (sv_pack_weights).
+
+    The first forward/backward of a module packs each weight individually and registers the request; from the next
+    refresh() on, every registered pack is produced by one launch into a flat buffer and get() only hands out views.
+    Packs made at forward time serve the backward of the same step (weights change only in optimizer.step())."""
+
+    def __init__(self):
+        self.tables = {}   # storage dtype -> dict(entries={key: [spec, w, kind, view]}, dirty, flat, descs, sig, nblocks)
+
+    def __deepcopy__(self, memo):
+        return PackCache()    # keyed by parameter identity: a copied module starts with an empty cache
+
+    def _table(self):
+        return self.tables.setdefault(_STATE["store"], dict(entries={}, dirty=False, flat=None, descs=None, sig=None, nblocks=0))
+
+    def get(self, spec, w, kind):
+        t = self._table()
+        key = (id(w), kind, spec.cin_mem, spec.cout_mem)
+        e = t["entries"].get(key)
+        if e is not None and e[3] is not None:
+            return e[3]
+        if e is None:
+            t["entries"][key] = [spec, w, kind, None]
+            t["dirty"] = True
+        return pack_one(spec, w, kind)
+
+    def refresh(self):
+        """(Re)build the descriptor table when the set of packs or a parameter's address changed, then pack everything."""
+        t = self._table()
+        ents = list(t["entries"].values())
+        if not ents:
+            return
+        sig = tuple(e[1].data_ptr() for e in ents)
+        if t["dirty"] or sig != t["sig"]:
+            per_block = int(hip.load().sv_pack_weights_block_elems())
+            dev = ents[0][1].device
+            offs, total, blocks = [], 0, 0
+            descs = (hip.PackDesc * len(ents))()
+            for i, (spec, w, kind, _) in enumerate(ents):
+                A, B, T, swap, pad, rows, inner = spec.pack_args(kind)
+                n = rows * T * inner
+                offs.append((total, n))
+                descs[i].src, descs[i].A, descs[i].B, descs[i].T, descs[i].swap = w.data_ptr(), A, B, T, swap
+                descs[i].rows_out, descs[i].inner_out, descs[i].block0 = rows, inner, blocks
+                blocks += (n + per_block - 1) // per_block
+                total += (n + 7) // 8 * 8          # every pack starts on a 16-byte boundary
+            flat = torch.empty(max(total, 8), dtype=_STATE["store"], device=dev)
+            esz = flat.element_size()
+            for i, (o, n) in enumerate(offs):
+                descs[i].dst = flat.data_ptr() + o * esz
+                ents[i][3] = flat[o:o + n]
+            raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+            t.update(dirty=False, flat=flat, descs=raw, sig=sig, nblocks=blocks)
+        call("sv_pack_weights", ptr(t["descs"]), len(ents), t["nblocks"], hip.ACT)
+
+
+def set_pack_cache(cache) -> None:
+    """Route ConvSpec.pack_fwd / pack_dgrad through `cache` (a PackCache, or None for one launch per pack)."""
+    _STATE["packs"] = cache
 
 
 def colsum(x, rows, cols, ld, out, accumulate=True):
