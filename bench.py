@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--math", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--storage", default="bf16", choices=["bf16", "f32"], help="HBM element type of the activations inside the modules")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail", action="store_true", help="print the per-geometry timing table of the contraction engine to stderr")
     ap.add_argument("--cpu-views", type=int, default=2)
     args = ap.parse_args()
 
@@ -180,6 +181,11 @@ def main():
                         for k, v in summ.items()},
             "model_flops_tflops_per_gpu": 3 * FWD_GFLOP_PER_VIEW.get(V, 19.4) * 1e9 * value / world / 1e12,
         }
+        if args.detail:
+            rows = sorted(tracer.detail().items(), key=lambda kv: -kv[1][1])
+            for (name, tag), (cnt, ms, fl, by) in rows[:60]:
+                print(f"{ms / args.steps:8.3f} ms/step  x{cnt / args.steps:5.1f}  {fl / max(ms, 1e-9) / 1e9:7.1f} TF/s  {by / max(ms, 1e-9) / 1e6:7.0f} GB/s  {name:18s} {tag}",
+                      file=sys.stderr)
         if not args.no_cpu_baseline:
             # host share of a one-GPU box is 16 cores (os.cpu_count() reports the whole node): cap the thread pool there
             try:

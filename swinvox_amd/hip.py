@@ -167,13 +167,13 @@ class Tracer:
         self.records = []          # (name, start_event, end_event, algorithmic_flops, algorithmic_bytes)
         self._open = None
 
-    def begin(self, name, flops=0.0, nbytes=0.0):
+    def begin(self, name, flops=0.0, nbytes=0.0, tag=""):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream())
-        self._open = (name, ev0, ev1, flops, nbytes)
+        self._open = (name, ev0, ev1, flops, nbytes, tag)
 
     def end(self):
-        name, ev0, ev1, flops, nbytes = self._open
+        ev1 = self._open[2]
         ev1.record(torch.cuda.current_stream())
         self.records.append(self._open)
         self._open = None
@@ -181,12 +181,21 @@ class Tracer:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, ev0, ev1, flops, nbytes in self.records:
+        for name, ev0, ev1, flops, nbytes, _ in self.records:
             d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += ev0.elapsed_time(ev1)
             d["flops"] += flops
             d["bytes"] += nbytes
+        return out
+
+
+    def detail(self):
+        """per (entry point, geometry tag): launches, total ms, algorithmic TFLOP/s and GB/s - call after summary()"""
+        out = {}
+        for name, ev0, ev1, flops, nbytes, tag in self.records:
+            d = out.setdefault((name, tag), [0, 0.0, 0.0, 0.0])
+            d[0] += 1; d[1] += ev0.elapsed_time(ev1); d[2] += flops; d[3] += nbytes
         return out
 
 

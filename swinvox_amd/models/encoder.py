@@ -121,6 +121,13 @@ class Encoder(HipModule):
         multi = self.cfg.NETWORK.USE_SWIN_T_MULTI_STAGE
         img = empty(I, 224 * 224, 3, like=images)
         ops.transpose(images, img, I, 3, 224 * 224)                       # NCHW -> NHWC (coalesced both ways)
+        cat = empty(I * 49, 512, like=img)                                 # [resnet 256 | swin 256] concat buffer
+        main = torch.cuda.current_stream()
+        side = ops.side_stream(img.device) if ops.overlap_enabled() else main
+        side.wait_stream(main)                                             # fork: the Swin branch runs beside the ResNet trunk
+        with torch.cuda.stream(side):
+            neck = self._swin_branch_fwd(img, cat, I, tr, sto, seeds, multi)
+        swin_tape = neck.pop()
         # ---- ResNet trunk
         x, g, c_stem = self._stem.forward(img, I, (1, 224, 224), tr)
         mp = empty(I * 56 * 56, 64, like=x)
@@ -135,33 +142,8 @@ class Encoder(HipModule):
         res_feat = x                                                       # [I*196, 1024]
         rr = empty(I * 196, 256, like=x)
         ops.linear_fwd(res_feat, I * 196, self._s_rr, self.resnet_reduce.weight, rr, bias=self.resnet_reduce.bias)
-        cat = empty(I * 49, 512, like=x)
         call("sv_avgpool2_fwd", ptr(rr), ptr(cat), I, 14, 14, 256, 512, 0)
-        # ---- Swin branch
-        feats, swin_tape = swin_forward(self.swin_transformer, img, I, tr, sto, seeds)
-        neck = []
-        if multi:
-            outs = []
-            for k, f in enumerate(feats):
-                hw = self.swin_transformer.out_spatial[k]
-                red = empty(I * hw * hw, 256, like=x)
-                ops.linear_fwd(f, I * hw * hw, self._s_red[k], self.swin_stage_reduces[k].weight, red, bias=self.swin_stage_reduces[k].bias)
-                y, gg, cc = red, (1, hw, hw), []
-                for cba in self._chains[k]:
-                    y, gg, c = cba.forward(y, I, gg, tr)
-                    cc.append(c)
-                assert gg == (1, 7, 7), "multi-stage neck must end at 7x7"
-                outs.append(y)
-                neck.append((f, red, cc))
-            cat_s = cat[:, 256:]
-            if len(outs) == 1:
-                outs = outs + [zeros(I * 49, 256, like=x)]
-            call("sv_add_n", ptr(outs[0]), ptr(outs[1]), ptr(outs[2]) if len(outs) > 2 else None, ptr(outs[3]) if len(outs) > 3 else None,
-                 ptr(cat_s), I * 49, 256, 512)
-        else:
-            f = feats if not isinstance(feats, list) else feats[-1]
-            ops.linear_fwd(f, I * 49, self._s_red1, self.swin_reduce.weight, cat, ldc=512, col_off=256, bias=self.swin_reduce.bias)
-            neck.append((f, None, None))
+        main.wait_stream(side)                                             # join
         # ---- cross-view attention
         c_cva = None
         y = cat
@@ -178,6 +160,35 @@ class Encoder(HipModule):
         tape = (B, V, c_stem, mp_idx, c_blocks, res_feat, rr, swin_tape, neck, c_cva, c_post) if save else None
         return ops.to_f32(out), tape
 
+    def _swin_branch_fwd(self, img, cat, I, tr, sto, seeds, multi):
+        """Swin backbone + multi-stage neck -> cat[:, 256:]; returns the neck tape with the backbone tape appended."""
+        feats, swin_tape = swin_forward(self.swin_transformer, img, I, tr, sto, seeds)
+        neck = []
+        if multi:
+            outs = []
+            for k, f in enumerate(feats):
+                hw = self.swin_transformer.out_spatial[k]
+                red = empty(I * hw * hw, 256, like=img)
+                ops.linear_fwd(f, I * hw * hw, self._s_red[k], self.swin_stage_reduces[k].weight, red, bias=self.swin_stage_reduces[k].bias)
+                y, gg, cc = red, (1, hw, hw), []
+                for cba in self._chains[k]:
+                    y, gg, c = cba.forward(y, I, gg, tr)
+                    cc.append(c)
+                assert gg == (1, 7, 7), "multi-stage neck must end at 7x7"
+                outs.append(y)
+                neck.append((f, red, cc))
+            cat_s = cat[:, 256:]
+            if len(outs) == 1:
+                outs = outs + [zeros(I * 49, 256, like=img)]
+            call("sv_add_n", ptr(outs[0]), ptr(outs[1]), ptr(outs[2]) if len(outs) > 2 else None, ptr(outs[3]) if len(outs) > 3 else None,
+                 ptr(cat_s), I * 49, 256, 512)
+        else:
+            f = feats if not isinstance(feats, list) else feats[-1]
+            ops.linear_fwd(f, I * 49, self._s_red1, self.swin_reduce.weight, cat, ldc=512, col_off=256, bias=self.swin_reduce.bias)
+            neck.append((f, None, None))
+        neck.append(swin_tape)
+        return neck
+
     def _bwd(self, tape, grads, in_needs, dout):
         B, V, c_stem, mp_idx, c_blocks, res_feat, rr, swin_tape, neck, c_cva, c_post = tape
         I = B * V
@@ -190,34 +201,38 @@ class Encoder(HipModule):
         dcat = dy                                                          # [I*49, 512]
         if c_cva is not None:
             dcat = self.cross_view_attention.cva_backward(c_cva, dcat, grads)
-        # ---- Swin neck
-        dcat_s = dcat[:, 256:]
-        if multi:
-            dfeats = []
-            for k, (f, red, cc) in enumerate(neck):
-                hw = self.swin_transformer.out_spatial[k]
-                d, ld = dcat_s, 512
-                for cba, c in zip(reversed(self._chains[k]), reversed(cc)):
-                    d = cba.backward(c, d, ld, grads)
-                    ld = 256
-                conv = self.swin_stage_reduces[k]
-                sp = self._s_red[k]
-                rows = I * hw * hw
-                sp.wgrad(d, f, rows, (1, 1, 1), grads[conv.weight], lddy=ld, db=grads[conv.bias])
-                df = empty(rows, sp.cin, like=dout)
-                sp.dgrad(d, rows, (1, 1, 1), sp.pack_dgrad(conv.weight), df, lddy=ld)
-                dfeats.append(df)
-        else:
-            f = neck[0][0]
-            sp = self._s_red1
-            sp.wgrad(dcat_s, f, I * 49, (1, 1, 1), grads[self.swin_reduce.weight], lddy=512, db=grads[self.swin_reduce.bias])
-            df = empty(I * 49, sp.cin, like=dout)
-            sp.dgrad(dcat_s, I * 49, (1, 1, 1), sp.pack_dgrad(self.swin_reduce.weight), df, lddy=512)
-            dfeats = [None] * (len(self.swin_transformer.layer_norm) - 1) + [df]
-            for i in range(len(dfeats) - 1):   # unused heads of the single-stage path receive zero gradient
-                hw, ch = self.swin_transformer.out_spatial[i], self.swin_transformer.out_channels[i]
-                dfeats[i] = zeros(I * hw * hw, ch, like=dout)
-        swin_backward(self.swin_transformer, swin_tape, dfeats, I, grads)
+        # ---- Swin neck + backbone on the side stream, ResNet branch on the main stream
+        main = torch.cuda.current_stream()
+        side = ops.side_stream(dcat.device) if ops.overlap_enabled() else main
+        side.wait_stream(main)                                             # fork (dcat and the zeroed gradient store are ready)
+        with torch.cuda.stream(side):
+            dcat_s = dcat[:, 256:]
+            if multi:
+                dfeats = []
+                for k, (f, red, cc) in enumerate(neck):
+                    hw = self.swin_transformer.out_spatial[k]
+                    d, ld = dcat_s, 512
+                    for cba, c in zip(reversed(self._chains[k]), reversed(cc)):
+                        d = cba.backward(c, d, ld, grads)
+                        ld = 256
+                    conv = self.swin_stage_reduces[k]
+                    sp = self._s_red[k]
+                    rows = I * hw * hw
+                    sp.wgrad(d, f, rows, (1, 1, 1), grads[conv.weight], lddy=ld, db=grads[conv.bias])
+                    df = empty(rows, sp.cin, like=dout)
+                    sp.dgrad(d, rows, (1, 1, 1), sp.pack_dgrad(conv.weight), df, lddy=ld)
+                    dfeats.append(df)
+            else:
+                f = neck[0][0]
+                sp = self._s_red1
+                sp.wgrad(dcat_s, f, I * 49, (1, 1, 1), grads[self.swin_reduce.weight], lddy=512, db=grads[self.swin_reduce.bias])
+                df = empty(I * 49, sp.cin, like=dout)
+                sp.dgrad(dcat_s, I * 49, (1, 1, 1), sp.pack_dgrad(self.swin_reduce.weight), df, lddy=512)
+                dfeats = [None] * (len(self.swin_transformer.layer_norm) - 1) + [df]
+                for i in range(len(dfeats) - 1):   # unused heads of the single-stage path receive zero gradient
+                    hw, ch = self.swin_transformer.out_spatial[i], self.swin_transformer.out_channels[i]
+                    dfeats[i] = zeros(I * hw * hw, ch, like=dout)
+            swin_backward(self.swin_transformer, swin_tape, dfeats, I, grads)
         # ---- ResNet branch
         drr = empty(I * 196, 256, like=dout)
         call("sv_avgpool2_bwd", ptr(dcat), ptr(drr), I, 14, 14, 256, 512, 0)
@@ -229,4 +244,5 @@ class Encoder(HipModule):
         dmp = empty(I * 112 * 112, 64, like=dout)                            # the gather-form max-pool backward writes every element
         call("sv_maxpool2d_bwd", ptr(d), ptr(mp_idx), ptr(dmp), I, 112, 112, 64)
         self._stem.backward(c_stem, dmp, 64, grads, need_dx=False)
+        main.wait_stream(side)                                             # join: every parameter gradient is complete
         return (None,)

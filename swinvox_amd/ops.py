@@ -187,7 +187,7 @@ class ConvSpec:
         nin, nout = n * in_grid[0] * in_grid[1] * in_grid[2], n * og[0] * og[1] * og[2]
         esz = 2.0 if _STATE["store"] == torch.bfloat16 else 4.0
         nbytes = esz * (nin * self.cin + nout * self.cout) + 4.0 * self.taps * self.cin * self.cout
-        tr.begin(name, flops, nbytes)
+        tr.begin(name, flops, nbytes, tag=f"n={n} grid={in_grid} cin={self.cin} cout={self.cout} k={self.k} s={self.s} t={int(self.transposed)}")
         call(name, *args)
         tr.end()
 
@@ -295,6 +295,30 @@ class PackCache:
             raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
             t.update(dirty=False, flat=flat, descs=raw, sig=sig, nblocks=blocks)
         call("sv_pack_weights", ptr(t["descs"]), len(ents), t["nblocks"], hip.ACT)
+
+
+_SIDE = {}
+
+
+def side_stream(dev) -> "torch.cuda.Stream":
+    """Second HIP stream of a device for the independent ResNet / Swin branches of the encoder (forward and backward).
+    Usage: side.wait_stream(main) [fork] ... with torch.cuda.stream(side): branch ... main.wait_stream(side) [join].
+    Allocator safety: tensors allocated while the side stream is current return to ITS pool and are only re-used by later
+    side-stream allocations, which follow a later fork (= wait on everything the main stream had queued); main-stream
+    tensors read by the side branch must stay referenced until the join (callers keep them in locals / the tape)."""
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
+def overlap_enabled() -> bool:
+    return _STATE.get("overlap", True)
+
+
+def set_overlap(on: bool) -> None:
+    """Run the encoder's two backbone branches on two HIP streams (default on)."""
+    _STATE["overlap"] = bool(on)
 
 
 def set_pack_cache(cache) -> None:
