@@ -128,6 +128,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_dt = time.perf_counter() - t0          # host time to ENQUEUE the K steps (the GPU may still be running)
     barrier()
     dt = time.perf_counter() - t0
     hip.TRACE = None
@@ -179,6 +180,7 @@ def main():
             "kernels": {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["ms"] / args.steps,
                             "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None}
                         for k, v in summ.items()},
+            "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
             "model_flops_tflops_per_gpu": 3 * FWD_GFLOP_PER_VIEW.get(V, 19.4) * 1e9 * value / world / 1e12,
         }
         if args.detail:

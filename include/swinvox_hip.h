@@ -152,7 +152,7 @@ int sv_scale_shift_act(const void* x, int ldx, const float* scale, const float* 
                        void* y, int ldy, long long M, int C, int act, float slope, int act_dtype, void* stream);
 int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const void* x, int ldx, const float* gamma,
               const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
-              void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws /* [2*C] doubles */,
+              void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws /* [2*C] doubles, ZERO on entry */,
               int act_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -672,8 +672,7 @@ extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const
   SV_REQUIRE(dz && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && sums_ws && M > 0 && C > 0, "bn_bwd: null/empty argument");
   SV_REQUIRE(act == SV_ACT_NONE || z, "bn_bwd: the activation mask needs the forward output z");
   SV_REQUIRE_ACT(act_dtype);
-  hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * C, s);
+  hipStream_t s = (hipStream_t)stream;   // sums_ws: zero on entry (caller-provided, e.g. a slice of one pre-zeroed arena)
   const bool vec = (C % 4 == 0) && (lddz % 4 == 0) && (ldx % 4 == 0) && (lddx % 4 == 0) && (!z || ldz % 4 == 0) && (!dres || lddres % 4 == 0) &&
                    aligned4(act_dtype, dz, z, x, dx, dres) && (((uintptr_t)save_mean | (uintptr_t)save_rstd) & 15) == 0;
   SV_DISPATCH_ACT(act_dtype,

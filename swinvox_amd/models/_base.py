@@ -23,16 +23,12 @@ class GradStore:
     def __init__(self, params: Sequence[torch.Tensor]):
         self.params = list(params)
         total = sum(p.numel() for p in self.params)
-        # every slice starts on a 16-byte boundary
-        offs, o = [], 0
-        for p in self.params:
-            offs.append(o)
-            o += (p.numel() + 3) // 4 * 4
-        self.flat = torch.zeros(max(o, 4), dtype=torch.float32, device=self.params[0].device) if self.params else None
+        self.flat = torch.zeros(max(total, 4), dtype=torch.float32, device=self.params[0].device) if self.params else None
         self._map: Dict[int, torch.Tensor] = {}
-        for p, of in zip(self.params, offs):
-            self._map[id(p)] = self.flat[of:of + p.numel()].view(p.shape)
-        del total
+        if self.params:   # one C++ call makes every parameter-shaped view of the flat buffer
+            views = torch._utils._unflatten_dense_tensors(self.flat[:total], self.params)
+            for p, v in zip(self.params, views):
+                self._map[id(p)] = v
 
     def __getitem__(self, p: torch.Tensor) -> torch.Tensor:
         return self._map[id(p)]
@@ -46,12 +42,18 @@ class _ModuleFn(torch.autograd.Function):
     def forward(ctx, mod, n_in, save, *args):
         inputs = args[:n_in]
         packs = mod.__dict__.setdefault("_packs", ops.PackCache())
+        arena = mod.__dict__.setdefault("_arena_f", ops.ZeroArena())
         ops.set_pack_cache(packs)
+        ops.set_arena(arena)
         try:
             packs.refresh()                      # every registered weight pack of the module in one launch
+            arena.begin(inputs[0].device)        # every BatchNorm statistic accumulator of the pass from one fill
             outs, tape = mod._fwd(*inputs, save=save)
         finally:
+            ops.bn_tick_flush()
+            arena.end()
             ops.set_pack_cache(None)
+            ops.set_arena(None)
         ctx.mod, ctx.tape, ctx.n_in = mod, tape, n_in
         ctx.store = ops.get_storage()
         ctx.in_needs = [isinstance(a, torch.Tensor) and a.requires_grad for a in inputs]
@@ -66,10 +68,15 @@ class _ModuleFn(torch.autograd.Function):
         if ops.get_storage() != ctx.store:
             raise RuntimeError("swinvox_amd: set_storage() changed between forward and backward")
         ops.set_pack_cache(mod.__dict__.setdefault("_packs", ops.PackCache()))
+        arena = mod.__dict__.setdefault("_arena_b", ops.ZeroArena())
+        ops.set_arena(arena)
         try:
+            arena.begin(douts[0].device if douts[0] is not None else grads.flat.device)
             d_inputs = mod._bwd(ctx.tape, grads, ctx.in_needs, *douts)
         finally:
+            arena.end()
             ops.set_pack_cache(None)
+            ops.set_arena(None)
         ctx.tape = None
         return (None, None, None) + tuple(d_inputs) + grads.as_tuple()
 
@@ -81,7 +88,13 @@ class HipModule(nn.Module):
     stochastic = True  # dropout / drop-path active in train() (set False for deterministic gradient parity tests)
 
     def _param_list(self) -> List[torch.Tensor]:
-        return list(self.parameters())
+        """Parameters in registration order (cached: walking the module tree costs ~1 ms per call on the encoder).  The
+        cache is checked against the parameter count so that added / removed parameters are picked up."""
+        pl = self.__dict__.get("_plist")
+        if pl is None or len(pl) != self.__dict__.get("_plist_n", -1):
+            pl = list(self.parameters())
+            self.__dict__["_plist"], self.__dict__["_plist_n"] = pl, len(pl)
+        return pl
 
     def _run(self, *inputs):
         hip.check_cuda(*inputs)

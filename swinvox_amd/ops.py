@@ -297,6 +297,49 @@ class PackCache:
         call("sv_pack_weights", ptr(t["descs"]), len(ents), t["nblocks"], hip.ACT)
 
 
+class ZeroArena:
+    """Zero-filled double scratch (BatchNorm statistic accumulators) for one module pass from ONE fill launch: the first
+    pass measures the demand with individual torch.zeros calls, later passes slice one pre-zeroed buffer."""
+
+    def __init__(self):
+        self.need, self.used, self.buf, self.off = 0, 0, None, 0
+
+    def begin(self, dev):
+        self.used, self.off = 0, 0
+        self.buf = torch.zeros(self.need, dtype=torch.float64, device=dev) if self.need else None
+
+    def take(self, n, dev):
+        self.used += n
+        if self.buf is not None and self.off + n <= self.buf.numel():
+            s = self.buf[self.off:self.off + n]
+            self.off += n
+            return s
+        return torch.zeros(n, dtype=torch.float64, device=dev)
+
+    def end(self):
+        self.need, self.buf = max(self.need, self.used), None
+
+    def __deepcopy__(self, memo):
+        return ZeroArena()
+
+
+def zeros_f64(n, dev):
+    a = _STATE.get("arena")
+    return a.take(n, dev) if a is not None else torch.zeros(n, dtype=torch.float64, device=dev)
+
+
+def set_arena(arena) -> None:
+    _STATE["arena"] = arena
+
+
+def bn_tick_flush() -> None:
+    """num_batches_tracked += 1 for every BatchNorm that ran since the last flush, in one foreach launch."""
+    lst = _STATE.get("bn_tick")
+    if lst:
+        torch._foreach_add_(lst, 1)
+    _STATE["bn_tick"] = []
+
+
 _SIDE = {}
 
 
@@ -367,14 +410,14 @@ class BatchNormState:
     def __init__(self, bn: torch.nn.Module, M: int, training: bool):
         self.bn, self.M, self.training, self.C = bn, M, training, bn.num_features
         dev = bn.weight.device
-        self.sums = torch.zeros(BN_SLOTS * 2 * self.C, dtype=torch.float64, device=dev) if training else None   # [slot][2C] doubles
+        self.sums = zeros_f64(BN_SLOTS * 2 * self.C, dev) if training else None   # [slot][2C] doubles
         buf = fempty(4 * self.C, device=dev)
         self.scale, self.shift, self.mean, self.rstd = buf[:self.C], buf[self.C:2 * self.C], buf[2 * self.C:3 * self.C], buf[3 * self.C:]
 
     def finalize(self):
         bn = self.bn
         if self.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+            _STATE.setdefault("bn_tick", []).append(bn.num_batches_tracked)   # += 1 in one foreach launch (bn_tick_flush)
         mom = bn.momentum if bn.momentum is not None else 0.1
         call("sv_bn_finalize", ptr(self.sums), self.M, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
              float(mom), float(bn.eps), 1 if self.training else 0, ptr(self.scale), ptr(self.shift), ptr(self.mean), ptr(self.rstd), self.C)
@@ -383,7 +426,7 @@ class BatchNormState:
         call("sv_scale_shift_act", ptr(x), ldx, ptr(self.scale), ptr(self.shift), ptr(residual), ldr, ptr(y), ldy, self.M, self.C, act, slope)
 
     def backward(self, dz, lddz, z, ldz, x, ldx, dx, lddx, dgamma, dbeta, act=ACT_NONE, slope=0.0, dres=None, lddres=0):
-        ws = torch.empty(2 * self.C, dtype=torch.float64, device=dz.device)
+        ws = zeros_f64(2 * self.C, dz.device)     # must be zero on entry
         call("sv_bn_bwd", ptr(dz), lddz, ptr(z), ldz, ptr(x), ldx, ptr(self.bn.weight), ptr(self.mean), ptr(self.rstd), self.M, self.C,
              act, slope, 1 if self.training else 0, ptr(dx), lddx, ptr(dres), lddres, ptr(dgamma), ptr(dbeta), ptr(ws))
 
