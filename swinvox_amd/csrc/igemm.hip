@@ -16,6 +16,7 @@
 // K-step 32 (fp32) or 64 (bf16); global->register prefetch of step k+1 under the MFMAs of step k
 // (register-staged: the gather needs per-element predication and an fp32->bf16 conversion).
 #include "common.h"
+#include <stdlib.h>
 
 namespace sv {
 
@@ -855,9 +856,11 @@ extern "C" int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, 
   const int BNw = narrow ? WTileNarrow::BN : (wide ? WTileWide::BN : WTileDefault::BN);
   const int BKs = math == SV_MATH_BF16 ? 64 : 32;
   const int tiles = cdiv(g->Co, BMw) * cdiv(Kout, BNw);
-  // enough splits to fill ~4 workgroups per CU, but at least 4 K-steps of work per split
-  long long splits = (1024 + tiles - 1) / tiles;
-  const long long max_splits = (Mll + 4 * BKs - 1) / (4 * BKs);
+  // one full wave of workgroups (2 per CU x 256 CUs) and >= 8 K-steps per split: measured best on the bench shapes (fewer,
+  // longer splits halve the fp32 atomic traffic of the epilogue; more than one wave only adds tail)
+  const int target_blocks = 512, min_ksteps = 8;
+  long long splits = (target_blocks + tiles - 1) / tiles;
+  const long long max_splits = (Mll + min_ksteps * BKs - 1) / (min_ksteps * BKs);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (splits > 65535) splits = 65535;

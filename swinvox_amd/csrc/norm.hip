@@ -5,17 +5,16 @@
 namespace sv {
 
 // ------------------------------------------------------------------------------------------------
-// token LayerNorm: one wave per row, row kept in registers (C <= 3072), two-pass variance.
+// token LayerNorm.  A row is handled by LPR lanes (16, 32 or 64) holding NV chunks of VEC elements each in registers
+// (two-pass variance), so a wave normalises 64/LPR rows at once and narrow rows (C = 96 ... 384) keep 75 % of the lanes
+// busy; VEC = 8 (16-byte accesses) with bf16 storage, 4 otherwise.
 // MERGE: the row is the PatchMerging gather of 4 tokens (order h0w0,h1w0,h0w1,h1w1) of a [I,H,W,C0] map.
 // ------------------------------------------------------------------------------------------------
-constexpr int LN_MAXV = 12;  // float4 chunks per lane -> C <= 64*4*12 = 3072
-
 struct MergeMap { int H, W, C0; };  // H,W of the un-merged map
 
 template <bool MERGE>
-__device__ __forceinline__ size_t ln_src_off(long long row, int chunk, int C, const MergeMap& mm) {
-  if constexpr (!MERGE) return (size_t)row * C + chunk * 4;
-  const int e = chunk * 4;
+__device__ __forceinline__ size_t ln_src_off(long long row, int e, int C, const MergeMap& mm) {   // e = first element of the chunk
+  if constexpr (!MERGE) return (size_t)row * C + e;
   const int blk = e / mm.C0, c = e - blk * mm.C0;   // blk = wp*2 + hp
   const int wp = blk >> 1, hp = blk & 1;
   const int W2 = mm.W >> 1, H2 = mm.H >> 1;
@@ -24,134 +23,182 @@ __device__ __forceinline__ size_t ln_src_off(long long row, int chunk, int C, co
   return ((size_t)(i * mm.H + 2 * y2 + hp) * mm.W + (2 * x2 + wp)) * mm.C0 + c;
 }
 
-template <bool MERGE, typename AT>
+template <int VEC, typename AT> struct LnIO;
+template <typename AT> struct LnIO<4, AT> {
+  static __device__ __forceinline__ void load(const AT* p, float* v) { const float4 q = ld4f(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+  static __device__ __forceinline__ void store(AT* p, const float* v) { st4f(p, make_float4(v[0], v[1], v[2], v[3])); }
+};
+template <> struct LnIO<8, __bf16> {
+  static __device__ __forceinline__ void load(const __bf16* p, float* v) {
+    const bf16x8 q = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)q[j];
+  }
+  static __device__ __forceinline__ void store(__bf16* p, const float* v) {
+    bf16x8 q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = (__bf16)v[j];
+    *reinterpret_cast<bf16x8*>(p) = q;
+  }
+};
+__device__ __forceinline__ void ldp(const float* p, float* v, int n) {   // n = 4 or 8 fp32 parameters
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  if (n == 8) { const float4 b = *reinterpret_cast<const float4*>(p + 4); v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
+}
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {   // sum over the LPR lanes that share a row
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <bool MERGE, typename AT, int VEC, int LPR, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const AT* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, AT* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      long long rows, int C, float eps, MergeMap mm) {
-  const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int nchunk = C >> 2;
-  float4 v[LN_MAXV];
+  constexpr int RPW = 64 / LPR;                       // rows per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gl = lane % LPR, gr = lane / LPR;
+  const long long row = ((long long)blockIdx.x * 4 + wave) * RPW + gr;
+  const bool rok = row < rows;
+  const int nchunk = C / VEC;
+  float v[NV][VEC];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nchunk) {
-      v[i] = ld4f(x + ln_src_off<MERGE>(row, ch, C, mm));
-      s += v[i].x + v[i].y + v[i].z + v[i].w;
+  for (int i = 0; i < NV; ++i) {
+    const int ch = gl + LPR * i;
+    if (rok && ch < nchunk) {
+      LnIO<VEC, AT>::load(x + ln_src_off<MERGE>(row, ch * VEC, C, mm), v[i]);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s += v[i][j];
     }
   }
-  const float mean = wave_sum(s) / C;
+  const float mean = group_sum<LPR>(s) / C;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nchunk) {
-      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-      q += a * a + b * b + c * c + d * d;
+  for (int i = 0; i < NV; ++i) {
+    const int ch = gl + LPR * i;
+    if (rok && ch < nchunk) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { const float a = v[i][j] - mean; q += a * a; }
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / C + eps);
-  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  const float rstd = rsqrtf(group_sum<LPR>(q) / C + eps);
+  if (rok && gl == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nchunk) {
-      const float4 g = *reinterpret_cast<const float4*>(gamma + ch * 4);
-      const float4 b = *reinterpret_cast<const float4*>(beta + ch * 4);
-      float4 o;
-      o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
-      o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      st4f(y + (size_t)row * C + ch * 4, o);
+  for (int i = 0; i < NV; ++i) {
+    const int ch = gl + LPR * i;
+    if (rok && ch < nchunk) {
+      float g[VEC], b[VEC], o[VEC];
+      ldp(gamma + ch * VEC, g, VEC); ldp(beta + ch * VEC, b, VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+      LnIO<VEC, AT>::store(y + (size_t)row * C + ch * VEC, o);
     }
   }
 }
 
 // backward: dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma; dgamma += dy*xhat, dbeta += dy.
-// A workgroup walks ROWS_PER_BLOCK rows (each wave a strided subset) so that the per-column partial sums
-// stay in registers and only one atomic per column per workgroup reaches HBM.
-constexpr int LN_BWD_ROWS = 64;
-
-template <bool MERGE, typename AT>
+// A workgroup walks rows_per_block rows (each row group a strided subset) with the per-column partial sums in registers;
+// they are folded through one LDS image (LDS atomics) and reach HBM as one atomic per column per workgroup.
+template <bool MERGE, typename AT, int VEC, int LPR, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, const AT* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, AT* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     long long rows, int C, MergeMap mm, int accumulate_dx) {
+                                                     long long rows, int C, MergeMap mm, int accumulate_dx, int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2*C]
+  constexpr int RPW = 64 / LPR, RPI = 4 * RPW;   // rows per wave / per workgroup iteration
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nchunk = C >> 2;
-  float4 dg[LN_MAXV], db[LN_MAXV], gm[LN_MAXV];
+  const int gl = lane % LPR, gr = lane / LPR;
+  const int nchunk = C / VEC;
+  for (int c = threadIdx.x; c < 2 * C; c += 256) red[c] = 0.f;
+  float dg[NV][VEC], db[NV][VEC], gm[NV][VEC];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    dg[i] = make_float4(0, 0, 0, 0); db[i] = make_float4(0, 0, 0, 0);
-    const int ch = lane + 64 * i;
-    gm[i] = ch < nchunk ? *reinterpret_cast<const float4*>(gamma + ch * 4) : make_float4(0, 0, 0, 0);
+  for (int i = 0; i < NV; ++i) {
+    const int ch = gl + LPR * i;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; gm[i][j] = 0.f; }
+    if (ch < nchunk) ldp(gamma + ch * VEC, gm[i], VEC);
   }
-  const long long r0 = (long long)blockIdx.x * LN_BWD_ROWS;
-  for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  for (int rr = wave * RPW + gr; rr < rows_per_block; rr += RPI) {
     const long long row = r0 + rr;
-    if (row >= rows) break;
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    float4 xh[LN_MAXV], g[LN_MAXV];
+    const bool rok = row < rows;                 // whole row groups stay in the loop: the group reductions need every lane
+    const float mean = rok ? mean_in[row] : 0.f, rstd = rok ? rstd_in[row] : 0.f;
+    float xh[NV][VEC], g[NV][VEC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int ch = lane + 64 * i;
-      if (ch < nchunk) {
-        const float4 xv = ld4f(x + ln_src_off<MERGE>(row, ch, C, mm));
-        const float4 d = ld4f(dy + (size_t)row * C + ch * 4);
-        xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd; xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
-        g[i].x = d.x * gm[i].x; g[i].y = d.y * gm[i].y; g[i].z = d.z * gm[i].z; g[i].w = d.w * gm[i].w;
-        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
-        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
-        dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
-        db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+    for (int i = 0; i < NV; ++i) {
+      const int ch = gl + LPR * i;
+      if (rok && ch < nchunk) {
+        float xv[VEC], d[VEC];
+        LnIO<VEC, AT>::load(x + ln_src_off<MERGE>(row, ch * VEC, C, mm), xv);
+        LnIO<VEC, AT>::load(dy + (size_t)row * C + ch * VEC, d);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          xh[i][j] = (xv[j] - mean) * rstd;
+          g[i][j] = d[j] * gm[i][j];
+          s1 += g[i][j]; s2 += g[i][j] * xh[i][j];
+          dg[i][j] += d[j] * xh[i][j]; db[i][j] += d[j];
+        }
       }
     }
-    const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+    const float m1 = group_sum<LPR>(s1) / C, m2 = group_sum<LPR>(s2) / C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int ch = lane + 64 * i;
-      if (ch < nchunk) {
-        float4 o;
-        o.x = rstd * (g[i].x - m1 - xh[i].x * m2); o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
-        o.z = rstd * (g[i].z - m1 - xh[i].z * m2); o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
-        AT* dst = dx + ln_src_off<MERGE>(row, ch, C, mm);
+    for (int i = 0; i < NV; ++i) {
+      const int ch = gl + LPR * i;
+      if (rok && ch < nchunk) {
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = rstd * (g[i][j] - m1 - xh[i][j] * m2);
+        AT* dst = dx + ln_src_off<MERGE>(row, ch * VEC, C, mm);
         if (accumulate_dx) {
-          const float4 old = ld4f(dst);
-          o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-        }
-        st4f(dst, o);
-      }
-    }
-  }
-  // fold the 4 waves' column partials through one LDS image (wave by wave), then one atomic per column
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
+          float old[VEC];
+          LnIO<VEC, AT>::load(dst, old);
 #pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < nchunk) {
-          float4 a = dg[i], b = db[i];
-          if (w > 0) {
-            const float4 oa = *reinterpret_cast<const float4*>(red + ch * 4), ob = *reinterpret_cast<const float4*>(red + C + ch * 4);
-            a.x += oa.x; a.y += oa.y; a.z += oa.z; a.w += oa.w;
-            b.x += ob.x; b.y += ob.y; b.z += ob.z; b.w += ob.w;
-          }
-          *reinterpret_cast<float4*>(red + ch * 4) = a;
-          *reinterpret_cast<float4*>(red + C + ch * 4) = b;
+          for (int j = 0; j < VEC; ++j) o[j] += old[j];
         }
+        LnIO<VEC, AT>::store(dst, o);
       }
     }
-    __syncthreads();
   }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int ch = gl + LPR * i;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { atomicAdd(red + ch * VEC + j, dg[i][j]); atomicAdd(red + C + ch * VEC + j, db[i][j]); }
+    }
+  }
+  __syncthreads();
   for (int c = threadIdx.x; c < 2 * C; c += 256) {
     if (c < C) atomicAdd(dgamma + c, red[c]); else atomicAdd(dbeta + c - C, red[c]);
   }
 }
+
+// (LPR, NV) for a row of `chunks` VEC-element chunks; NV is rounded up to an instantiated count
+static inline bool ln_shape(int chunks, int& lpr, int& nv) {
+  lpr = chunks <= 16 ? 16 : (chunks <= 32 ? 32 : 64);
+  const int need = (chunks + lpr - 1) / lpr;
+  static const int opts[] = {1, 2, 3, 4, 6, 12};
+  for (int o : opts) if (need <= o) { nv = o; return true; }
+  return false;
+}
+#define SV_LN_DISPATCH(LPR_, NV_, ...)                                                       \
+  do {                                                                                       \
+    if (LPR_ == 16) { constexpr int LPR = 16, NV = 1; __VA_ARGS__ }                          \
+    else if (LPR_ == 32) { constexpr int LPR = 32, NV = 1; __VA_ARGS__ }                     \
+    else if (NV_ == 1) { constexpr int LPR = 64, NV = 1; __VA_ARGS__ }                       \
+    else if (NV_ == 2) { constexpr int LPR = 64, NV = 2; __VA_ARGS__ }                       \
+    else if (NV_ == 3) { constexpr int LPR = 64, NV = 3; __VA_ARGS__ }                       \
+    else if (NV_ == 4) { constexpr int LPR = 64, NV = 4; __VA_ARGS__ }                       \
+    else if (NV_ == 6) { constexpr int LPR = 64, NV = 6; __VA_ARGS__ }                       \
+    else { constexpr int LPR = 64, NV = 12; __VA_ARGS__ }                                    \
+  } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // long-row LayerNorm with a full-size affine (Swin stage heads: nn.LayerNorm([C,H,W]) on NHWC data whose
@@ -549,21 +596,52 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __rest
 
 using namespace sv;
 
+template <bool MERGE, typename AT, int VEC>
+static void ln_fwd_launch(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, long long rows, int C,
+                          float eps, MergeMap mm, hipStream_t s) {
+  int lpr, nv;
+  ln_shape(C / VEC, lpr, nv);
+  const int rpb = 4 * (64 / lpr);   // rows per workgroup
+  SV_LN_DISPATCH(lpr, nv, hipLaunchKernelGGL((ln_fwd_kernel<MERGE, AT, VEC, LPR, NV>), dim3(cdiv(rows, rpb)), dim3(256), 0, s,
+                                             static_cast<const AT*>(x), gamma, beta, static_cast<AT*>(y), mean, rstd, rows, C, eps, mm););
+}
+template <bool MERGE, typename AT, int VEC>
+static void ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
+                          float* dbeta, long long rows, int C, MergeMap mm, int accumulate_dx, hipStream_t s) {
+  int lpr, nv;
+  ln_shape(C / VEC, lpr, nv);
+  const int rpi = 4 * (64 / lpr);                       // rows per workgroup iteration
+  long long rpb = rows / 1024; if (rpb < rpi) rpb = rpi; if (rpb > 256) rpb = 256;   // >= ~1024 workgroups where the row count allows
+  rpb = (rpb + rpi - 1) / rpi * rpi;
+  const size_t lds = sizeof(float) * 2 * C;
+  SV_LN_DISPATCH(lpr, nv, hipLaunchKernelGGL((ln_bwd_kernel<MERGE, AT, VEC, LPR, NV>), dim3(cdiv(rows, rpb)), dim3(256), lds, s,
+                                             static_cast<const AT*>(dy), static_cast<const AT*>(x), gamma, mean, rstd, static_cast<AT*>(dx),
+                                             dgamma, dbeta, rows, C, mm, accumulate_dx, (int)rpb););
+}
+// VEC = 8 needs bf16 storage, 8-element channel groups (also of the un-merged map) and 16-byte aligned tensors
+static inline bool ln_vec8(int act_dtype, int C, int merge_H, const void* a, const void* b, const void* c = nullptr) {
+  return act_dtype == SV_BF16 && C % 8 == 0 && (merge_H == 0 || (C / 4) % 8 == 0) &&
+         (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0;
+}
+
 extern "C" int sv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                 long long rows, int C, float eps, int merge_H, int merge_W, int act_dtype, void* stream) {
   SV_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0, "layernorm_fwd: null/empty argument");
-  SV_REQUIRE(C % 4 == 0 && C <= 64 * 4 * LN_MAXV, "layernorm_fwd: C=%d must be a multiple of 4 and <= %d", C, 64 * 4 * LN_MAXV);
+  SV_REQUIRE(C % 4 == 0 && C <= 3072, "layernorm_fwd: C=%d must be a multiple of 4 and <= 3072", C);
   SV_REQUIRE_ACT(act_dtype);
+  SV_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "layernorm_fwd: gamma/beta must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  MergeMap mm{merge_H, merge_W, merge_H > 0 ? C / 4 : 0};
+  if (merge_H > 0) SV_REQUIRE(merge_H % 2 == 0 && merge_W % 2 == 0 && C % 16 == 0, "layernorm_fwd(merge): H,W must be even and C a multiple of 16");
+  const bool v8 = ln_vec8(act_dtype, C, merge_H, x, y);
   if (merge_H > 0) {
-    SV_REQUIRE(merge_H % 2 == 0 && merge_W % 2 == 0 && C % 16 == 0, "layernorm_fwd(merge): H,W must be even and C a multiple of 16");
-    MergeMap mm{merge_H, merge_W, C / 4};
-    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL((ln_fwd_kernel<true, AT>), dim3(cdiv(rows, 4)), dim3(256), 0, s, static_cast<const AT*>(x), gamma, beta,
-                                                  static_cast<AT*>(y), mean, rstd, rows, C, eps, mm););
+    if (v8) ln_fwd_launch<true, __bf16, 8>(x, gamma, beta, y, mean, rstd, rows, C, eps, mm, s);
+    else if (act_dtype == SV_BF16) ln_fwd_launch<true, __bf16, 4>(x, gamma, beta, y, mean, rstd, rows, C, eps, mm, s);
+    else ln_fwd_launch<true, float, 4>(x, gamma, beta, y, mean, rstd, rows, C, eps, mm, s);
   } else {
-    MergeMap mm{0, 0, 0};
-    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL((ln_fwd_kernel<false, AT>), dim3(cdiv(rows, 4)), dim3(256), 0, s, static_cast<const AT*>(x), gamma, beta,
-                                                  static_cast<AT*>(y), mean, rstd, rows, C, eps, mm););
+    if (v8) ln_fwd_launch<false, __bf16, 8>(x, gamma, beta, y, mean, rstd, rows, C, eps, mm, s);
+    else if (act_dtype == SV_BF16) ln_fwd_launch<false, __bf16, 4>(x, gamma, beta, y, mean, rstd, rows, C, eps, mm, s);
+    else ln_fwd_launch<false, float, 4>(x, gamma, beta, y, mean, rstd, rows, C, eps, mm, s);
   }
   return check_launch("sv_layernorm_fwd");
 }
@@ -572,18 +650,20 @@ extern "C" int sv_layernorm_bwd(const void* dy, const void* x, const float* gamm
                                 void* dx, float* dgamma, float* dbeta, long long rows, int C, int merge_H, int merge_W,
                                 int accumulate_dx, int act_dtype, void* stream) {
   SV_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "layernorm_bwd: null/empty argument");
-  SV_REQUIRE(C % 4 == 0 && C <= 64 * 4 * LN_MAXV, "layernorm_bwd: C=%d unsupported", C);
+  SV_REQUIRE(C % 4 == 0 && C <= 3072, "layernorm_bwd: C=%d unsupported", C);
   SV_REQUIRE_ACT(act_dtype);
+  SV_REQUIRE(((uintptr_t)gamma & 15) == 0, "layernorm_bwd: gamma must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = sizeof(float) * 2 * C;
+  MergeMap mm{merge_H, merge_W, merge_H > 0 ? C / 4 : 0};
+  const bool v8 = ln_vec8(act_dtype, C, merge_H, dy, x, dx);
   if (merge_H > 0) {
-    MergeMap mm{merge_H, merge_W, C / 4};
-    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL((ln_bwd_kernel<true, AT>), dim3(cdiv(rows, LN_BWD_ROWS)), dim3(256), lds, s, static_cast<const AT*>(dy),
-                                                  static_cast<const AT*>(x), gamma, mean, rstd, static_cast<AT*>(dx), dgamma, dbeta, rows, C, mm, accumulate_dx););
+    if (v8) ln_bwd_launch<true, __bf16, 8>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, s);
+    else if (act_dtype == SV_BF16) ln_bwd_launch<true, __bf16, 4>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, s);
+    else ln_bwd_launch<true, float, 4>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, s);
   } else {
-    MergeMap mm{0, 0, 0};
-    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL((ln_bwd_kernel<false, AT>), dim3(cdiv(rows, LN_BWD_ROWS)), dim3(256), lds, s, static_cast<const AT*>(dy),
-                                                  static_cast<const AT*>(x), gamma, mean, rstd, static_cast<AT*>(dx), dgamma, dbeta, rows, C, mm, accumulate_dx););
+    if (v8) ln_bwd_launch<false, __bf16, 8>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, s);
+    else if (act_dtype == SV_BF16) ln_bwd_launch<false, __bf16, 4>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, s);
+    else ln_bwd_launch<false, float, 4>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, s);
   }
   return check_launch("sv_layernorm_bwd");
 }
