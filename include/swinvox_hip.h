@@ -135,8 +135,10 @@ int sv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long 
  * ---------------------------------------------------------------------------------------------- */
 int sv_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                      long long rows, int C, float eps, int merge_H, int merge_W, int act_dtype, void* stream);
+/* workspace: sv_layernorm_bwd_workspace_floats(C) floats, ZERO on entry (slot-spread dgamma/dbeta partial sums + ticket) */
+size_t sv_layernorm_bwd_workspace_floats(int C);
 int sv_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                     void* dx, float* dgamma, float* dbeta, long long rows, int C, int merge_H, int merge_W,
+                     void* dx, float* dgamma, float* dbeta, float* workspace, long long rows, int C, int merge_H, int merge_W,
                      int accumulate_dx, int act_dtype, void* stream);
 size_t sv_ln_image_workspace_floats(int I, int L);
 int sv_ln_image_fwd(const void* x, const float* w, const float* b, void* y, float* meanrstd, float* workspace,
@@ -150,9 +152,10 @@ int sv_bn_finalize(const double* sums, long long count, const float* gamma, cons
                    float* save_mean, float* save_rstd, int C, void* stream);
 int sv_scale_shift_act(const void* x, int ldx, const float* scale, const float* shift, const void* residual, int ldr,
                        void* y, int ldy, long long M, int C, int act, float slope, int act_dtype, void* stream);
+size_t sv_bn_bwd_workspace_doubles(int C);   /* size of sums_ws below */
 int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const void* x, int ldx, const float* gamma,
               const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
-              void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws /* [2*C] doubles, ZERO on entry */,
+              void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws /* sv_bn_bwd_workspace_doubles(C) doubles, ZERO on entry */,
               int act_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

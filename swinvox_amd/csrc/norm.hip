@@ -10,6 +10,11 @@ namespace sv {
 // busy; VEC = 8 (16-byte accesses) with bf16 storage, 4 otherwise.
 // MERGE: the row is the PatchMerging gather of 4 tokens (order h0w0,h1w0,h0w1,h1w1) of a [I,H,W,C0] map.
 // ------------------------------------------------------------------------------------------------
+// Contention-free reductions across workgroups: partial sums go (atomically) into one of NSLOT accumulator images chosen by
+// the workgroup index and a tiny second kernel folds the images.  (A "last workgroup folds" ticket would need a device-scope
+// __threadfence(), which writes back the whole per-XCD L2 on this chip - measured 100+ us per call.)
+constexpr int BN_BWD_SLOTS = 16, LN_BWD_SLOTS = 32;
+
 struct MergeMap { int H, W, C0; };  // H,W of the un-merged map
 
 template <bool MERGE>
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, AT* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     long long rows, int C, MergeMap mm, int accumulate_dx, int rows_per_block) {
+                                                     long long rows, int C, MergeMap mm, int accumulate_dx, int rows_per_block,
+                                                     float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2*C]
   constexpr int RPW = 64 / LPR, RPI = 4 * RPW;   // rows per wave / per workgroup iteration
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -175,9 +181,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * C; c += 256) {
-    if (c < C) atomicAdd(dgamma + c, red[c]); else atomicAdd(dbeta + c - C, red[c]);
-  }
+  // one atomic per column per workgroup into one of LN_BWD_SLOTS images; the last workgroup folds them into dgamma / dbeta
+  float* slot = ws + (size_t)(blockIdx.x % LN_BWD_SLOTS) * 2 * C;
+  for (int c = threadIdx.x; c < 2 * C; c += 256) atomicAdd(slot + c, red[c]);
+}
+// dgamma[c] += sum_slot ws[slot][c], dbeta[c] += sum_slot ws[slot][C + c]
+__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float* __restrict__ ws, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * C) return;
+  float a = 0.f;
+#pragma unroll 8
+  for (int sl = 0; sl < LN_BWD_SLOTS; ++sl) a += ws[(size_t)sl * 2 * C + c];
+  if (c < C) dgamma[c] += a; else dbeta[c - C] += a;
 }
 
 // (LPR, NV) for a row of `chunks` VEC-element chunks; NV is rounded up to an instantiated count
@@ -412,6 +427,17 @@ __global__ __launch_bounds__(256) void scale_shift_act_scalar_kernel(const AT* _
   }
 }
 
+// fold the BatchNorm backward slots: fin[c] = sum_slot ws[slot][c] (c < 2C), dgamma += fin[C + c], dbeta += fin[c]
+__global__ __launch_bounds__(256) void bn_bwd_fold_kernel(double* __restrict__ ws, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * C) return;
+  double a = 0.0;
+#pragma unroll
+  for (int sl = 0; sl < BN_BWD_SLOTS; ++sl) a += ws[(size_t)sl * 2 * C + c];
+  ws[(size_t)BN_BWD_SLOTS * 2 * C + c] = a;
+  if (c < C) dbeta[c] += (float)a; else dgamma[c - C] += (float)a;
+}
+
 // backward pass 1: per channel s1 = sum(dz'), s2 = sum(dz' * xhat), dz' = dz * act'(z) (mask from the OUTPUT z)
 template <typename AT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const AT* __restrict__ dz, int lddz, const AT* __restrict__ z, int ldz,
@@ -449,8 +475,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const AT* __restrict
   r1[rl][threadIdx.x & 63] = s1; r2[rl][threadIdx.x & 63] = s2;
   __syncthreads();
   if (rl == 0 && c < C) {
-    atomicAdd(sums + c, r1[0][threadIdx.x] + r1[1][threadIdx.x] + r1[2][threadIdx.x] + r1[3][threadIdx.x]);
-    atomicAdd(sums + C + c, r2[0][threadIdx.x] + r2[1][threadIdx.x] + r2[2][threadIdx.x] + r2[3][threadIdx.x]);
+    double* slot = sums + (size_t)(blockIdx.y % BN_BWD_SLOTS) * 2 * C;
+    atomicAdd(slot + c, r1[0][threadIdx.x] + r1[1][threadIdx.x] + r1[2][threadIdx.x] + r1[3][threadIdx.x]);
+    atomicAdd(slot + C + c, r2[0][threadIdx.x] + r2[1][threadIdx.x] + r2[2][threadIdx.x] + r2[3][threadIdx.x]);
   }
 }
 
@@ -465,6 +492,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const AT* __restrict_
                                                            int lddres, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const long long total = M * C;
   const double invM = 1.0 / (double)M;
+  sums += (size_t)BN_BWD_SLOTS * 2 * C;     // the folded image written by the reduce pass
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / C; const int c = (int)(i - r * C);
     float d = ldf(dz + (size_t)r * lddz + c);
@@ -482,8 +510,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const AT* __restrict_
     }
     stf(dx + (size_t)r * lddx + c, o);
   }
-  if (blockIdx.x == 0)
-    for (int c = threadIdx.x; c < C; c += 256) { dgamma[c] += (float)sums[C + c]; dbeta[c] += (float)sums[c]; }
 }
 
 // 16-byte variant of the above (C and every row stride multiples of 4): 4 channels per thread
@@ -497,6 +523,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const AT* __restr
   const int cv = C >> 2;
   const long long total = M * cv;
   const double invM = 1.0 / (double)M;
+  sums += (size_t)BN_BWD_SLOTS * 2 * C;     // the folded image written by the reduce pass
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / cv; const int c = (int)(i - r * cv) * 4;
     const float4 dv = ld4f(dz + (size_t)r * lddz + c);
@@ -524,8 +551,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const AT* __restr
     }
     st4f(dx + (size_t)r * lddx + c, make_float4(o[0], o[1], o[2], o[3]));
   }
-  if (blockIdx.x == 0)
-    for (int c = threadIdx.x; c < C; c += 256) { dgamma[c] += (float)sums[C + c]; dbeta[c] += (float)sums[c]; }
 }
 
 // vector variant of pass 1 (C and the row strides multiples of 4): a thread owns 4 adjacent channels of a strided row
@@ -587,7 +612,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __rest
     if (cc < C) {
       double a = 0.0;
       for (int l = 0; l < RL; ++l) a += red[l * G + q][k];
-      atomicAdd(sums + (k < 4 ? 0 : C) + cc, a);
+      atomicAdd(sums + (size_t)(blockIdx.y % BN_BWD_SLOTS) * 2 * C + (k < 4 ? 0 : C) + cc, a);
     }
   }
 }
@@ -607,7 +632,7 @@ static void ln_fwd_launch(const void* x, const float* gamma, const float* beta, 
 }
 template <bool MERGE, typename AT, int VEC>
 static void ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
-                          float* dbeta, long long rows, int C, MergeMap mm, int accumulate_dx, hipStream_t s) {
+                          float* dbeta, long long rows, int C, MergeMap mm, int accumulate_dx, float* ws, hipStream_t s) {
   int lpr, nv;
   ln_shape(C / VEC, lpr, nv);
   const int rpi = 4 * (64 / lpr);                       // rows per workgroup iteration
@@ -616,7 +641,8 @@ static void ln_bwd_launch(const void* dy, const void* x, const float* gamma, con
   const size_t lds = sizeof(float) * 2 * C;
   SV_LN_DISPATCH(lpr, nv, hipLaunchKernelGGL((ln_bwd_kernel<MERGE, AT, VEC, LPR, NV>), dim3(cdiv(rows, rpb)), dim3(256), lds, s,
                                              static_cast<const AT*>(dy), static_cast<const AT*>(x), gamma, mean, rstd, static_cast<AT*>(dx),
-                                             dgamma, dbeta, rows, C, mm, accumulate_dx, (int)rpb););
+                                             dgamma, dbeta, rows, C, mm, accumulate_dx, (int)rpb, ws););
+  hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, ws, C, dgamma, dbeta);
 }
 // VEC = 8 needs bf16 storage, 8-element channel groups (also of the un-merged map) and 16-byte aligned tensors
 static inline bool ln_vec8(int act_dtype, int C, int merge_H, const void* a, const void* b, const void* c = nullptr) {
@@ -646,10 +672,12 @@ extern "C" int sv_layernorm_fwd(const void* x, const float* gamma, const float* 
   return check_launch("sv_layernorm_fwd");
 }
 
+extern "C" size_t sv_layernorm_bwd_workspace_floats(int C) { return (size_t)LN_BWD_SLOTS * 2 * C + 2; }
+
 extern "C" int sv_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                void* dx, float* dgamma, float* dbeta, long long rows, int C, int merge_H, int merge_W,
+                                void* dx, float* dgamma, float* dbeta, float* workspace, long long rows, int C, int merge_H, int merge_W,
                                 int accumulate_dx, int act_dtype, void* stream) {
-  SV_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "layernorm_bwd: null/empty argument");
+  SV_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace && rows > 0, "layernorm_bwd: null/empty argument");
   SV_REQUIRE(C % 4 == 0 && C <= 3072, "layernorm_bwd: C=%d unsupported", C);
   SV_REQUIRE_ACT(act_dtype);
   SV_REQUIRE(((uintptr_t)gamma & 15) == 0, "layernorm_bwd: gamma must be 16-byte aligned");
@@ -657,13 +685,13 @@ extern "C" int sv_layernorm_bwd(const void* dy, const void* x, const float* gamm
   MergeMap mm{merge_H, merge_W, merge_H > 0 ? C / 4 : 0};
   const bool v8 = ln_vec8(act_dtype, C, merge_H, dy, x, dx);
   if (merge_H > 0) {
-    if (v8) ln_bwd_launch<true, __bf16, 8>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, s);
-    else if (act_dtype == SV_BF16) ln_bwd_launch<true, __bf16, 4>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, s);
-    else ln_bwd_launch<true, float, 4>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, s);
+    if (v8) ln_bwd_launch<true, __bf16, 8>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, workspace, s);
+    else if (act_dtype == SV_BF16) ln_bwd_launch<true, __bf16, 4>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, workspace, s);
+    else ln_bwd_launch<true, float, 4>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, workspace, s);
   } else {
-    if (v8) ln_bwd_launch<false, __bf16, 8>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, s);
-    else if (act_dtype == SV_BF16) ln_bwd_launch<false, __bf16, 4>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, s);
-    else ln_bwd_launch<false, float, 4>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, s);
+    if (v8) ln_bwd_launch<false, __bf16, 8>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, workspace, s);
+    else if (act_dtype == SV_BF16) ln_bwd_launch<false, __bf16, 4>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, workspace, s);
+    else ln_bwd_launch<false, float, 4>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, mm, accumulate_dx, workspace, s);
   }
   return check_launch("sv_layernorm_bwd");
 }
@@ -745,6 +773,8 @@ extern "C" int sv_scale_shift_act(const void* x, int ldx, const float* scale, co
   return check_launch("sv_scale_shift_act");
 }
 
+extern "C" size_t sv_bn_bwd_workspace_doubles(int C) { return (size_t)(BN_BWD_SLOTS + 1) * 2 * C + 2; }
+
 extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const void* x, int ldx, const float* gamma,
                          const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
                          void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws, int act_dtype,
@@ -752,7 +782,7 @@ extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const
   SV_REQUIRE(dz && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && sums_ws && M > 0 && C > 0, "bn_bwd: null/empty argument");
   SV_REQUIRE(act == SV_ACT_NONE || z, "bn_bwd: the activation mask needs the forward output z");
   SV_REQUIRE_ACT(act_dtype);
-  hipStream_t s = (hipStream_t)stream;   // sums_ws: zero on entry (caller-provided, e.g. a slice of one pre-zeroed arena)
+  hipStream_t s = (hipStream_t)stream;   // sums_ws: sv_bn_bwd_workspace_doubles(C) doubles, ZERO on entry (e.g. a slice of one pre-zeroed arena)
   const bool vec = (C % 4 == 0) && (lddz % 4 == 0) && (ldx % 4 == 0) && (lddx % 4 == 0) && (!z || ldz % 4 == 0) && (!dres || lddres % 4 == 0) &&
                    aligned4(act_dtype, dz, z, x, dx, dres) && (((uintptr_t)save_mean | (uintptr_t)save_rstd) & 15) == 0;
   SV_DISPATCH_ACT(act_dtype,
@@ -766,6 +796,7 @@ extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const
       const long long rpb = (M + splits - 1) / splits;
       hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope,
                          sums_ws, rpb, G);
+      hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);
       long long blocks = (M * (C / 4) + 255) / 256; if (blocks > 8192) blocks = 8192;
       hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
                          act, slope, training, dx_, lddx, dres_, lddres, dgamma, dbeta);
@@ -775,6 +806,7 @@ extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const
       const long long maxs = (M + 63) / 64; if (splits > maxs) splits = maxs;
       const long long rpb = (M + splits - 1) / splits;
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope, sums_ws, rpb);
+      hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);
       long long blocks = (M * C + 255) / 256; if (blocks > 8192) blocks = 8192;
       hipLaunchKernelGGL(bn_bwd_apply_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
                          act, slope, training, dx_, lddx, dres_, lddres, dgamma, dbeta);

@@ -64,7 +64,9 @@ _PROTOS = {
     "sv_colsum": (_I, [_P, _I, _I, _I, _P, _I]),
     "sv_cast": (_I, [_P, _I, _P, _I, _L]),
     "sv_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _I]),
-    "sv_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I]),
+    "sv_layernorm_bwd_workspace_floats": (C.c_size_t, None, [_I]),
+    "sv_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I]),
+    "sv_bn_bwd_workspace_doubles": (C.c_size_t, None, [_I]),
     "sv_ln_image_workspace_floats": (C.c_size_t, None, [_I, _I]),
     "sv_ln_image_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U]),
     "sv_ln_image_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U]),

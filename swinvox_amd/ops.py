@@ -18,6 +18,7 @@ from .hip import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, Epilogue, Geom, call, 
 
 _STATE = {"math": hip.MATH_F32, "store": torch.float32}
 BN_SLOTS = 16   # SV_BN_SLOTS of include/swinvox_hip.h
+BN_BWD_SLOTS, LN_BWD_SLOTS = 16, 32   # slot counts behind sv_bn_bwd_workspace_doubles / sv_layernorm_bwd_workspace_floats
 
 
 def set_math(mode: str) -> None:
@@ -400,7 +401,8 @@ def layernorm_fwd(x, gamma, beta, rows, Cdim, merge_hw=(0, 0), eps=1e-5):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cdim, merge_hw=(0, 0), accumulate_dx=False):
-    call("sv_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), rows, Cdim,
+    ws = zeros_f64(LN_BWD_SLOTS * Cdim + 1, dy.device)     # sv_layernorm_bwd_workspace_floats(C) floats, zero on entry
+    call("sv_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), rows, Cdim,
          merge_hw[0], merge_hw[1], 1 if accumulate_dx else 0)
 
 
@@ -426,7 +428,7 @@ class BatchNormState:
         call("sv_scale_shift_act", ptr(x), ldx, ptr(self.scale), ptr(self.shift), ptr(residual), ldr, ptr(y), ldy, self.M, self.C, act, slope)
 
     def backward(self, dz, lddz, z, ldz, x, ldx, dx, lddx, dgamma, dbeta, act=ACT_NONE, slope=0.0, dres=None, lddres=0):
-        ws = zeros_f64(2 * self.C, dz.device)     # must be zero on entry
+        ws = zeros_f64((BN_BWD_SLOTS + 1) * 2 * self.C + 2, dz.device)     # sv_bn_bwd_workspace_doubles(C), zero on entry
         call("sv_bn_bwd", ptr(dz), lddz, ptr(z), ldz, ptr(x), ldx, ptr(self.bn.weight), ptr(self.mean), ptr(self.rstd), self.M, self.C,
              act, slope, 1 if self.training else 0, ptr(dx), lddx, ptr(dres), lddres, ptr(dgamma), ptr(dbeta), ptr(ws))
 
