@@ -99,13 +99,17 @@ int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, float* dw, 
  * bf16 operands.  x: channels-last positions with row stride ldx, cin_load (multiple of 4) elements read per position,
  * zero-extended to 16*groups channels; w_bf16: [16*ntiles16][27][16*groups] bf16 (forward: rows = output channels;
  * data-gradient: rows = input channels, taps flipped).  Writes out[pos*ldc + col_off + n] for n < cout
- * (= residual + value when residual != NULL); optional per-channel statistics as in sv_epilogue.stats. */
+ * (= residual[pos*ldr + n] + value when residual != NULL); optional per-channel statistics as in sv_epilogue.stats
+ * (ntiles16 == 1 only).  When ldc, col_off (and ldr) are multiples of 4 and the row has room, the columns
+ * cout .. roundup4(cout)-1 are treated as PADDING of the row and written too (zero, + residual): 8/16-byte row stores.
+ * Persistent kernel: one workgroup walks many 4x8x8 bricks, prefetching the next brick while it contracts the current one. */
 int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups, const void* w_bf16, int ntiles16,
                     const float* bias, void* out, int ldc, int col_off, int cout, const void* residual, int ldr,
                     double* stats, int I, int D, int H, int W, int act_dtype, void* stream);
-/* dw[co][ci][27] += sum_vox dy[vox][co] * x[vox + tap][c]; memory channel c maps to ci = (c / c_stride)*c_valid + c % c_stride */
+/* dw[co][ci][27] += sum_vox dy[vox][co] * x[vox + tap][c]; memory channel c maps to ci = (c / c_stride)*c_valid + c % c_stride;
+ * optional dbias[co] += sum_vox dy[vox][co] */
 int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int groups, const void* dy, int lddy, int cout_load,
-                      float* dw, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W, int act_dtype,
+                      float* dw, float* dbias, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W, int act_dtype,
                       void* stream);
 /* dst[a][t][b] (b padded with zeros to pad_to) from the fp32 parameter src[a][b][t] (swap=0), or dst[b][t][a..pad_to] (swap=1);
  * dst elements are out_dtype (SV_F32 / SV_BF16) */

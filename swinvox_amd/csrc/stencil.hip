@@ -1,135 +1,194 @@
 // LDS-halo MFMA stencils for the <=16-channel 3x3x3 convolutions of the 32^3 tail (merger, models/merger.py:20-54).
 //
 // The generic implicit-GEMM engine gathers every (voxel, tap) operand row from L2 (27 x 48 B per voxel) and pads the
-// 9 output channels to a 64-wide tile; here a workgroup owns a 4x8x8 brick of voxels, stages the brick + halo ONCE in LDS
+// 9 output channels to a 64-wide tile; here a workgroup owns 4x8x8 bricks of voxels, stages a brick + halo ONCE in LDS
 // as bf16 [position][16 channels] (32 B rows) and feeds the MFMA straight from it:
 //   forward / data-gradient:  out[vox, n] = sum_{tap, c} x[vox + tap, c] * w[n, tap, c]
 //       A fragment (voxel rows, 8 consecutive channels of one tap) = ONE 16-byte LDS read; weights [16n][27][16G] in LDS.
 //   weight gradient:          dw[co, tap, c] += sum_vox dy[vox, co] * x[vox + tap, c]
 //       the contraction runs over VOXELS: both fragments (8 consecutive x-positions per lane) come from the
-//       [position][channel] images through ds_read_b64_tr_b16; the four waves split the 27 taps; workgroups are
-//       persistent over bricks so the 27 x 81 partial sums reach HBM once per workgroup.
+//       [position][channel] images through ds_read_b64_tr_b16; the four waves split the 27 taps.
+// Both kernels are PERSISTENT over bricks: weights / partial sums are set up once per workgroup, and the next brick's
+// halo is prefetched into registers while the current one is contracted (global latency hidden behind the MFMA loop).
+// The forward epilogue stages the tile in LDS and stores whole channel rows per voxel (8-byte vectors).
 // bf16 operands, fp32 accumulate (these kernels serve set_math("bf16"); exact-fp32 parity runs use the generic engine).
 #include "common.h"
 
 namespace sv {
 
-constexpr int TZ = 4, TY = 8, TX = 8;                 // brick of output voxels per workgroup
+constexpr int TZ = 4, TY = 8, TX = 8;                 // brick of output voxels per tile
 constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;  // with halo
 constexpr int HPOS = HZ * HY * HX;                    // 600 positions
+constexpr int NVOX = TZ * TY * TX;                    // 256 voxels = one per thread in the epilogue
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+
+__device__ __forceinline__ bf16x4 to_bf16x4(float4 v) {
+  bf16x4 b;
+  b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+  return b;
+}
+__device__ __forceinline__ bf16x4 to_bf16x4(bf16x4 v) { return v; }
+
+struct TileId { int img, z0, y0, x0; };
+__device__ __forceinline__ TileId tile_of(int t, int D, int H, int W) {
+  const int tz = D / TZ, ty = H / TY, tx = W / TX;
+  TileId r;
+  r.x0 = (t % tx) * TX; t /= tx; r.y0 = (t % ty) * TY; t /= ty; r.z0 = (t % tz) * TZ; r.img = t / tz;
+  return r;
+}
+
+// one thread's share of a halo brick [HPOS][16*G], kept as raw 4-element vectors between the prefetch and the LDS store
+template <int G, typename AT>
+struct HaloRegs {
+  static constexpr int C = 16 * G, VPP = C / 4, N = (HPOS * VPP + 255) / 256;
+  typename V4<AT>::type r[N];
+  __device__ __forceinline__ void load(const AT* __restrict__ x, int ldx, int cin_load, const TileId& t, int D, int H, int W, int tid) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int i = tid + 256 * k;
+      typename V4<AT>::type q = V4<AT>::zero();
+      if (i < HPOS * VPP) {
+        const int h = i / VPP, v = i - h * VPP;
+        const int hx = h % HX; const int t2 = h / HX; const int hy = t2 % HY; const int hz = t2 / HY;
+        const int z = t.z0 - 1 + hz, y = t.y0 - 1 + hy, xx = t.x0 - 1 + hx;
+        if (v * 4 < cin_load && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W)
+          q = V4<AT>::load(x + ((((size_t)t.img * D + z) * H + y) * W + xx) * (size_t)ldx + v * 4);
+      }
+      r[k] = q;
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* Xs, int tid) const {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int i = tid + 256 * k;
+      if (i < HPOS * VPP) *reinterpret_cast<bf16x4*>(Xs + i * 4) = to_bf16x4(r[k]);   // [h][v*4] == linear i*4
+    }
+  }
+};
 
 template <typename AT>
 struct StencilArgsT {                         // AT = storage element of the activations (x, out, residual)
   const AT* x; int ldx; int cin_load;         // input positions [I*D*H*W][ldx], cin_load (multiple of 4, <= 16*G) elements loaded per position
   const __bf16* w;                            // packed weights [NT*16][27][16*G]
-  const float* bias; AT* out; int ldc; int col_off; int cout;   // columns written: n < cout
+  const float* bias; AT* out; int ldc; int col_off; int cout;   // columns written: n < cout (+ zero pads up to a multiple of 4, see header)
   const AT* residual; int ldr;                // optional: out = residual + val (same column window)
   double* stats;                              // optional [SV_BN_SLOTS][2*cout]
-  int I, D, H, W;
+  int I, D, H, W, ntiles;
 };
-
-// stage the halo brick of one tile into LDS as bf16 [HPOS][16*G]; out-of-volume positions and channels >= cin_load are zero
-template <int G, typename AT>
-__device__ __forceinline__ void load_halo(__bf16* Xs, const AT* x, int ldx, int cin_load, int img, int z0, int y0, int x0,
-                                          int D, int H, int W, int tid) {
-  constexpr int C = 16 * G, V4 = C / 4;
-  for (int i = tid; i < HPOS * V4; i += 256) {
-    const int h = i / V4, v = i - h * V4;
-    const int hx = h % HX; const int t = h / HX; const int hy = t % HY; const int hz = t / HY;
-    const int z = z0 - 1 + hz, y = y0 - 1 + hy, xx = x0 - 1 + hx;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (v * 4 < cin_load && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W)
-      q = ld4f(x + ((((size_t)img * D + z) * H + y) * W + xx) * (size_t)ldx + v * 4);
-    st4f(Xs + h * C + v * 4, q);
-  }
-}
 
 template <int G, int NT, typename AT>
 __global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgsT<AT> p) {
   constexpr int C = 16 * G, KTOT = 27 * C, KPAD = (KTOT + 31) / 32 * 32, NSTEP = KPAD / 32;
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[HPOS * C];
+  constexpr int NCOL = NT * 16, LDC = NCOL + 1;
+  constexpr int XS_BYTES = HPOS * C * 2, CS_BYTES = NVOX * LDC * 4;
+  __shared__ __attribute__((aligned(16))) char xc[XS_BYTES > CS_BYTES ? XS_BYTES : CS_BYTES];   // halo brick, then the output tile
   __shared__ __attribute__((aligned(16))) __bf16 Ws[NT * 16 * KPAD];
-  __shared__ float red[4 * NT * 16 * 2];
+  __shared__ float red[16 * 16 * 2];
+  __bf16* Xs = reinterpret_cast<__bf16*>(xc);
+  float* Cs = reinterpret_cast<float*>(xc);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int tz = p.D / TZ, ty = p.H / TY, tx = p.W / TX;
-  int t = blockIdx.x;
-  const int bx = t % tx; t /= tx; const int by = t % ty; t /= ty; const int bz = t % tz; const int img = t / tz;
-  const int z0 = bz * TZ, y0 = by * TY, x0 = bx * TX;
 
-  // weights -> LDS (rows padded with zeros to a multiple of 32 k)
+  // weights -> LDS once per workgroup (16-byte vectors; rows padded with zeros to a multiple of 32 k)
   for (int i = tid; i < NT * 16 * KPAD / 8; i += 256) {
     const int n = (i * 8) / KPAD, k = (i * 8) - n * KPAD;
-    bf16x8 v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (k + j < KTOT) ? p.w[(size_t)n * KTOT + k + j] : (__bf16)0.f;
+    bf16x8 v = VecN<__bf16, 8>::zero();
+    if (k < KTOT) v = *reinterpret_cast<const bf16x8*>(p.w + (size_t)n * KTOT + k);
     *reinterpret_cast<bf16x8*>(Ws + n * KPAD + k) = v;
   }
-  load_halo<G, AT>(Xs, p.x, p.ldx, p.cin_load, img, z0, y0, x0, p.D, p.H, p.W, tid);
+  const int cs4 = (p.cout + 3) & ~3;
+  const bool vec_out = (p.ldc & 3) == 0 && (p.col_off & 3) == 0 && p.col_off + cs4 <= p.ldc && (!p.residual || ((p.ldr & 3) == 0 && cs4 <= p.ldr));
+  const int sn = tid & 15, srg = tid >> 4;           // statistics: column sn, voxel group srg (16 voxels)
+  const float sbias = (p.bias && sn < p.cout) ? p.bias[sn] : 0.f;
+  float st1 = 0.f, st2 = 0.f;
+
+  HaloRegs<G, AT> hr;
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) { hr.load(p.x, p.ldx, p.cin_load, tile_of(tile, p.D, p.H, p.W), p.D, p.H, p.W, tid); hr.store(Xs, tid); }
   __syncthreads();
-
-  // this wave: z-slice `wave`; M-tile mt = rows y = 2mt, 2mt+1; fragment row r = lane&15 -> (yy = r>>3, xx = r&7)
-  f32x4 acc[4][NT];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int yy = lr >> 3, xx = lr & 7;
-  int abase[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) abase[mt] = (wave * HY + 2 * mt + yy) * HX + xx;   // halo index of (z, y, x) shifted by tap (0,0,0)
-#pragma unroll 2
-  for (int s = 0; s < NSTEP; ++s) {
-    const int kb = s * 32 + lg * 8;
-    int tap = kb / C; const int c = kb - tap * C;
-    if (tap > 26) tap = 26;                       // padded k: weights are zero there, any valid address will do
-    const int dz = tap / 9, dy = (tap - dz * 9) / 3, dx = tap - dz * 9 - dy * 3;
-    const int off = (dz * HY + dy) * HX + dx;
-    bf16x8 b[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(Ws + (nt * 16 + lr) * KPAD + kb);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xs + (abase[mt] + off) * C + c);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[mt][nt], 0, 0, 0);
-    }
-  }
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    const TileId t = tile_of(tile, p.D, p.H, p.W);
+    const int next = tile + gridDim.x;
+    if (next < p.ntiles) hr.load(p.x, p.ldx, p.cin_load, tile_of(next, p.D, p.H, p.W), p.D, p.H, p.W, tid);   // in flight during the MFMA loop
 
-  // epilogue: C element (row = lg*4 + j -> voxel, col = lr -> output channel)
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + lr;
-    const bool nok = n < p.cout;
-    const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    // this wave: z-slice `wave`; M-tile mt = rows y = 2mt, 2mt+1; fragment row r = lane&15 -> (yy = r>>3, xx = r&7)
+    f32x4 acc[4][NT];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = lg * 4 + j;
-        const int z = z0 + wave, y = y0 + 2 * mt + (r >> 3), x = x0 + (r & 7);
-        if (nok) {
-          const size_t pos = (((size_t)img * p.D + z) * p.H + y) * p.W + x;
-          float v = acc[mt][nt][j] + bias;
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int abase[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) abase[mt] = (wave * HY + 2 * mt + yy) * HX + xx;   // halo index of (z, y, x) shifted by tap (0,0,0)
+#pragma unroll 2
+    for (int s = 0; s < NSTEP; ++s) {
+      const int kb = s * 32 + lg * 8;
+      int tap = kb / C; const int c = kb - tap * C;
+      if (tap > 26) tap = 26;                       // padded k: weights are zero there, any valid address will do
+      const int dz = tap / 9, dy = (tap - dz * 9) / 3, dx = tap - dz * 9 - dy * 3;
+      const int off = (dz * HY + dy) * HX + dx;
+      bf16x8 b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(Ws + (nt * 16 + lr) * KPAD + kb);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xs + (abase[mt] + off) * C + c);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                 // every wave is done reading the brick: the tile may overwrite it
+    // accumulators -> Cs[voxel][column]; C element (row = lg*4 + j -> voxel, col = lr -> output channel)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = lg * 4 + j;
+          const int vid = (wave * TY + 2 * mt + (r >> 3)) * TX + (r & 7);
+          Cs[vid * LDC + nt * 16 + lr] = acc[mt][nt][j];
+        }
+    __syncthreads();
+    {  // one voxel per thread: whole channel row (+ bias, + residual)
+      const int vz = tid >> 6, vy = (tid >> 3) & 7, vx = tid & 7;
+      const size_t pos = (((size_t)t.img * p.D + t.z0 + vz) * p.H + t.y0 + vy) * p.W + t.x0 + vx;
+      const float* crow = Cs + tid * LDC;
+      if (vec_out) {
+        for (int n0 = 0; n0 < cs4; n0 += 4) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (n0 + j < p.cout) ? crow[n0 + j] + (p.bias ? p.bias[n0 + j] : 0.f) : 0.f;
+          if (p.residual) {
+            const float4 rv = ld4f(p.residual + pos * p.ldr + n0);
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          }
+          st4f(p.out + pos * p.ldc + p.col_off + n0, make_float4(v[0], v[1], v[2], v[3]));
+        }
+      } else {
+        for (int n = 0; n < p.cout; ++n) {
+          float v = crow[n] + (p.bias ? p.bias[n] : 0.f);
           if (p.residual) v += ldf(p.residual + pos * p.ldr + n);
           stf(p.out + pos * p.ldc + p.col_off + n, v);
-          s1 += v; s2 += v * v;
         }
       }
-    if (p.stats) {
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (lg == 0) { red[((wave * NT + nt) * 16 + lr) * 2] = s1; red[((wave * NT + nt) * 16 + lr) * 2 + 1] = s2; }
     }
-  }
-  if (p.stats) {
+    if (NT == 1 && p.stats && sn < p.cout) {         // per-channel sum / sum of squares of the stored values
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const float v = Cs[(srg * 16 + k) * LDC + sn] + sbias; st1 += v; st2 += v * v; }
+    }
+    __syncthreads();                                 // the tile is consumed: the next brick may land in LDS
+    if (next < p.ntiles) hr.store(Xs, tid);
     __syncthreads();
-    if (tid < NT * 16 && tid < p.cout) {
+  }
+  if (NT == 1 && p.stats) {
+    red[(srg * 16 + sn) * 2] = st1; red[(srg * 16 + sn) * 2 + 1] = st2;
+    __syncthreads();
+    if (tid < 16 && tid < p.cout) {
       float a = 0.f, b = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { a += red[((w * NT * 16) + tid) * 2]; b += red[((w * NT * 16) + tid) * 2 + 1]; }
+      for (int g2 = 0; g2 < 16; ++g2) { a += red[(g2 * 16 + tid) * 2]; b += red[(g2 * 16 + tid) * 2 + 1]; }
       double* st = p.stats + (size_t)(blockIdx.x % SV_BN_SLOTS) * 2 * p.cout;
       atomicAdd(st + tid, (double)a);
       atomicAdd(st + p.cout + tid, (double)b);
@@ -142,6 +201,7 @@ struct StencilWArgsT {
   const AT* x; int ldx; int cin_load;        // gathered operand (conv input), memory channels = 16*G (zero-padded)
   const AT* dy; int lddy; int cout_load;     // anchor operand (output gradient), <= 16 memory channels
   float* dw;                                 // native [cout][cin][27], accumulated with atomics
+  float* dbias;                              // optional [cout]: += sum_vox dy[vox][co]
   int cout, cin;                             // real channel counts
   int c_stride, c_valid;                     // memory channel c -> real channel (c / c_stride) * c_valid + c % c_stride, valid if c % c_stride < c_valid
   int I, D, H, W, ntiles;
@@ -151,10 +211,10 @@ template <int G, typename AT>
 __global__ __launch_bounds__(256) void stencil3_wgrad_kernel(const StencilWArgsT<AT> p) {
   constexpr int C = 16 * G;
   __shared__ __attribute__((aligned(16))) __bf16 Xs[HPOS * C];
-  __shared__ __attribute__((aligned(16))) __bf16 Ds[TZ * TY * TX * 16];
+  __shared__ __attribute__((aligned(16))) __bf16 Ds[NVOX * 16];
+  __shared__ float bred[16 * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4, q = lr >> 2, pp = lr & 3;
-  const int tz = p.D / TZ, ty = p.H / TY, tx = p.W / TX;
   // taps of this wave: t = wave + 4*i, i < NTAP
   const int ntap = (27 - wave + 3) / 4;
   f32x4 acc[7][G];
@@ -162,22 +222,45 @@ __global__ __launch_bounds__(256) void stencil3_wgrad_kernel(const StencilWArgsT
   for (int i = 0; i < 7; ++i)
 #pragma unroll
     for (int gg = 0; gg < G; ++gg) acc[i][gg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;                                   // bias gradient: column tid&15, voxel group tid>>4
 
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    int t = tile;
-    const int bx = t % tx; t /= tx; const int by = t % ty; t /= ty; const int bz = t % tz; const int img = t / tz;
-    const int z0 = bz * TZ, y0 = by * TY, x0 = bx * TX;
-    __syncthreads();   // previous tile's LDS reads are done
-    load_halo<G, AT>(Xs, p.x, p.ldx, p.cin_load, img, z0, y0, x0, p.D, p.H, p.W, tid);
-    for (int i = tid; i < TZ * TY * TX * 4; i += 256) {     // dy brick -> [voxel][16] bf16
+  HaloRegs<G, AT> hr;
+  typename V4<AT>::type dr[4];                        // dy brick: NVOX voxels x 4 vectors = 4 per thread
+  auto load_dy = [&](const TileId& t) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + 256 * k;
       const int v = i >> 2, c4 = i & 3;
       const int xx = v % TX; const int t2 = v / TX; const int yy = t2 % TY; const int zz = t2 / TY;
-      float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+      typename V4<AT>::type qv = V4<AT>::zero();
       if (c4 * 4 < p.cout_load)
-        qv = ld4f(p.dy + ((((size_t)img * p.D + z0 + zz) * p.H + y0 + yy) * p.W + x0 + xx) * (size_t)p.lddy + c4 * 4);
-      st4f(Ds + v * 16 + c4 * 4, qv);
+        qv = V4<AT>::load(p.dy + ((((size_t)t.img * p.D + t.z0 + zz) * p.H + t.y0 + yy) * p.W + t.x0 + xx) * (size_t)p.lddy + c4 * 4);
+      dr[k] = qv;
     }
-    __syncthreads();
+  };
+  auto store_dy = [&]() {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<bf16x4*>(Ds + (tid + 256 * k) * 4) = to_bf16x4(dr[k]);   // [voxel][16] == linear i*4
+  };
+
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) {
+    const TileId t = tile_of(tile, p.D, p.H, p.W);
+    hr.load(p.x, p.ldx, p.cin_load, t, p.D, p.H, p.W, tid); load_dy(t);
+    hr.store(Xs, tid); store_dy();
+  }
+  __syncthreads();
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < p.ntiles) {
+      const TileId t = tile_of(next, p.D, p.H, p.W);
+      hr.load(p.x, p.ldx, p.cin_load, t, p.D, p.H, p.W, tid); load_dy(t);     // in flight during the MFMA loop
+    }
+    if (p.dbias) {
+      const int c = tid & 15, vg = tid >> 4;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) bsum += (float)Ds[(vg * 16 + k) * 16 + c];
+    }
     // 8 chunks of 32 voxels: chunk = (z, half); k = 8*g + j  <->  (y = 4*half + g, x = j)
 #pragma unroll 1
     for (int ch = 0; ch < 8; ++ch) {
@@ -202,6 +285,19 @@ __global__ __launch_bounds__(256) void stencil3_wgrad_kernel(const StencilWArgsT
           }
         }
       }
+    }
+    __syncthreads();                                   // the brick is consumed
+    if (next < p.ntiles) { hr.store(Xs, tid); store_dy(); }
+    __syncthreads();
+  }
+  if (p.dbias) {
+    bred[tid] = bsum;                                  // [voxel group][column]
+    __syncthreads();
+    if (tid < 16 && tid < p.cout) {
+      float a = 0.f;
+#pragma unroll
+      for (int g2 = 0; g2 < 16; ++g2) a += bred[g2 * 16 + tid];
+      atomicAdd(p.dbias + tid, a);
     }
   }
   // C element: row = lg*4 + j -> co, col = lr -> memory channel 16*gg + lr
@@ -243,16 +339,23 @@ extern "C" int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups,
   if (int rc = stencil_check(I, D, H, W)) return rc;
   SV_REQUIRE(cin_load % 4 == 0 && cin_load <= 16 * groups && ldx % 4 == 0 && ldx >= cin_load, "stencil3_fwd: bad input channels (cin_load=%d ldx=%d groups=%d)", cin_load, ldx, groups);
   SV_REQUIRE(cout > 0 && cout <= 16 * ntiles16 && ldc >= col_off + cout, "stencil3_fwd: bad output window");
-  SV_REQUIRE(((uintptr_t)x & (act_dtype == SV_BF16 ? 7 : 15)) == 0 && ((uintptr_t)w_bf16 & 15) == 0, "stencil3_fwd: operands must be aligned to 4 elements");
-  const int blocks = I * (D / TZ) * (H / TY) * (W / TX);
+  SV_REQUIRE(!stats || ntiles16 == 1, "stencil3_fwd: statistics need a single 16-column tile");
+  const uintptr_t amask = act_dtype == SV_BF16 ? 7 : 15;
+  SV_REQUIRE(((uintptr_t)x & amask) == 0 && ((uintptr_t)w_bf16 & 15) == 0, "stencil3_fwd: operands must be aligned to 4 elements");
+  SV_REQUIRE((ldc & 3) != 0 || (((uintptr_t)out | (uintptr_t)residual) & amask) == 0,
+             "stencil3_fwd: out/residual must be aligned to 4 elements when ldc is a multiple of 4");
+  const int ntiles = I * (D / TZ) * (H / TY) * (W / TX);
   hipStream_t s = (hipStream_t)stream;
   if (!((groups == 1 && ntiles16 == 1) || (groups == 3 && ntiles16 == 1) || (groups == 1 && ntiles16 == 3))) {
     set_error("stencil3_fwd: unsupported (groups=%d, ntiles16=%d)", groups, ntiles16);
     return SV_ERR_INVALID;
   }
+  // persistent grid: as many workgroups as stay resident (LDS-bound: ~3 per CU with one channel group, 1 with three)
+  const int resident = 256 * (groups == 1 && ntiles16 == 1 ? 3 : 1);
+  const int blocks = ntiles < resident ? ntiles : resident;
   SV_DISPATCH_ACT(act_dtype,
     StencilArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, (const __bf16*)w_bf16, bias, static_cast<AT*>(out), ldc, col_off, cout,
-                       static_cast<const AT*>(residual), ldr, stats, I, D, H, W};
+                       static_cast<const AT*>(residual), ldr, stats, I, D, H, W, ntiles};
     if (groups == 1 && ntiles16 == 1) hipLaunchKernelGGL((stencil3_fwd_kernel<1, 1, AT>), dim3(blocks), dim3(256), 0, s, a);
     else if (groups == 3) hipLaunchKernelGGL((stencil3_fwd_kernel<3, 1, AT>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((stencil3_fwd_kernel<1, 3, AT>), dim3(blocks), dim3(256), 0, s, a););
@@ -260,8 +363,8 @@ extern "C" int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups,
 }
 
 extern "C" int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int groups, const void* dy, int lddy, int cout_load,
-                                 float* dw, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W, int act_dtype,
-                                 void* stream) {
+                                 float* dw, float* dbias, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W,
+                                 int act_dtype, void* stream) {
   SV_REQUIRE(x && dy && dw, "stencil3_wgrad: null argument");
   SV_REQUIRE_ACT(act_dtype);
   if (int rc = stencil_check(I, D, H, W)) return rc;
@@ -271,10 +374,12 @@ extern "C" int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int group
   SV_REQUIRE((((uintptr_t)x | (uintptr_t)dy) & (act_dtype == SV_BF16 ? 7 : 15)) == 0, "stencil3_wgrad: operands must be aligned to 4 elements");
   SV_REQUIRE(groups == 1 || groups == 3, "stencil3_wgrad: unsupported groups=%d", groups);
   const int ntiles = I * (D / TZ) * (H / TY) * (W / TX);
-  const int blocks = ntiles < 1024 ? ntiles : 1024;
+  const int resident = 256 * (groups == 1 ? 4 : 2);
+  const int blocks = ntiles < resident ? ntiles : resident;
   hipStream_t s = (hipStream_t)stream;
   SV_DISPATCH_ACT(act_dtype,
-    StencilWArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, static_cast<const AT*>(dy), lddy, cout_load, dw, cout, cin, c_stride, c_valid, I, D, H, W, ntiles};
+    StencilWArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, static_cast<const AT*>(dy), lddy, cout_load, dw, dbias, cout, cin, c_stride, c_valid,
+                        I, D, H, W, ntiles};
     if (groups == 1) hipLaunchKernelGGL((stencil3_wgrad_kernel<1, AT>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((stencil3_wgrad_kernel<3, AT>), dim3(blocks), dim3(256), 0, s, a););
   return check_launch("sv_stencil3_wgrad");

@@ -94,13 +94,19 @@ class Merger(HipModule):
         conv, I = self._layer(li)[0], dy.shape[0] // VOX
         if ops.get_math() == "bf16":
             call("sv_stencil3_wgrad", ptr(x), ldx, 48 if li == 4 else 12, 3 if li == 4 else 1, ptr(dy), lddy, lddy if lddy <= 12 else 12,
-                 ptr(grads[conv.weight]), conv.out_channels, conv.in_channels, 12 if li == 4 else 16, 9, I, 32, 32, 32)
+                 ptr(grads[conv.weight]), ptr(grads[conv.bias]), conv.out_channels, conv.in_channels, 12 if li == 4 else 16, 9, I, 32, 32, 32)
         elif li == 4:
             dw5p = fzeros(9, 48, 27, like=dy)
             self._s5.wgrad(dy, x, I, G, dw5p, lddy=lddy, ldx=ldx)
             grads[conv.weight].view(9, 36, 27).copy_(dw5p[:, self._cat_cols])
         else:
             self._spec(li).wgrad(dy, x, I, G, grads[conv.weight], lddy=lddy, ldx=ldx)
+
+    def _bias_grad(self, dy, M, C, ld, db):
+        """conv bias gradient = column sums of dy: folded into the stencil weight-gradient kernel in bf16 math, a separate
+        column-sum kernel next to the generic engine otherwise."""
+        if ops.get_math() != "bf16":
+            ops.colsum(dy, M, C, ld, db)
 
     # ---- forward / backward chains -------------------------------------------------------------------------
     def _fwd(self, raw, vol, save):
@@ -113,20 +119,20 @@ class Merger(HipModule):
         ctx14, xin, ldi = [], x12, 12
         for k in range(4):
             bn = self._layer(k)[1]
-            y = empty(M, 9, like=vol)
+            y = empty(M, 12, like=vol)              # 9 channels + 3 pad columns: whole-row vector stores / loads
             st = BatchNormState(bn, M, tr)
-            self._conv_fwd(k, xin, ldi, y, 9, st.sums)
+            self._conv_fwd(k, xin, ldi, y, 12, st.sums)
             st.finalize()
             z = cat[:, 12 * k:]
-            st.apply(y, 9, z, 48, ACT_LRELU, sl)
+            st.apply(y, 12, z, 48, ACT_LRELU, sl)
             ctx14.append((xin, ldi, y, z, st))
             xin, ldi = z, 48
-        y5 = empty(M, 9, like=vol)
+        y5 = empty(M, 12, like=vol)
         st5 = BatchNormState(self.layer5[1], M, tr)
-        self._conv_fwd(4, cat, 48, y5, 9, st5.sums, w5p)
+        self._conv_fwd(4, cat, 48, y5, 12, st5.sums, w5p)
         st5.finalize()
         z5 = zeros(M, 12, like=vol)
-        st5.apply(y5, 9, z5, 12, ACT_LRELU, sl)
+        st5.apply(y5, 12, z5, 12, ACT_LRELU, sl)
         y6 = empty(M, 1, like=vol)
         st6 = BatchNormState(self.layer6[1], M, tr)
         self._conv_fwd(5, z5, 12, y6, 1, st6.sums)
@@ -149,15 +155,15 @@ class Merger(HipModule):
         conv6, bn6 = self.layer6[0], self.layer6[1]
         dy6 = zeros(M, 4, like=vol)
         st6.backward(dwl, 1, wl, 1, y6, 1, dy6, 4, grads[bn6.weight], grads[bn6.bias], ACT_LRELU, sl)
-        ops.colsum(dy6, M, 1, 4, grads[conv6.bias])
+        self._bias_grad(dy6, M, 1, 4, grads[conv6.bias])
         self._conv_wgrad(5, dy6, 4, z5, 12, grads)
         dz5 = zeros(M, 12, like=vol)
         self._conv_dgrad(5, dy6, 4, dz5, 12, False)
         # ---- layer 5
         conv5, bn5 = self.layer5[0], self.layer5[1]
         dy5 = zeros(M, 12, like=vol)
-        st5.backward(dz5, 12, z5, 12, y5, 9, dy5, 12, grads[bn5.weight], grads[bn5.bias], ACT_LRELU, sl)
-        ops.colsum(dy5, M, 9, 12, grads[conv5.bias])
+        st5.backward(dz5, 12, z5, 12, y5, 12, dy5, 12, grads[bn5.weight], grads[bn5.bias], ACT_LRELU, sl)
+        self._bias_grad(dy5, M, 9, 12, grads[conv5.bias])
         self._conv_wgrad(4, dy5, 12, cat, 48, grads)
         dcat = zeros(M, 48, like=vol)   # data-gradient wrt the 48-wide concat buffer (pad columns receive zero weights)
         self._conv_dgrad(4, dy5, 12, dcat, 48, False, w5p)
@@ -168,8 +174,8 @@ class Merger(HipModule):
             xin, ldi, y, z, st = ctx14[k]
             dzk = dcat[:, 12 * k:]
             dy = zeros(M, 12, like=vol)
-            st.backward(dzk, 48, z, 48, y, 9, dy, 12, grads[bn.weight], grads[bn.bias], ACT_LRELU, sl)
-            ops.colsum(dy, M, 9, 12, grads[conv.bias])
+            st.backward(dzk, 48, z, 48, y, 12, dy, 12, grads[bn.weight], grads[bn.bias], ACT_LRELU, sl)
+            self._bias_grad(dy, M, 9, 12, grads[conv.bias])
             self._conv_wgrad(k, dy, 12, xin, ldi, grads)
             if k > 0:   # accumulate into the previous layer's slot of dcat
                 self._conv_dgrad(k, dy, 12, dcat[:, 12 * (k - 1):], 48, True)

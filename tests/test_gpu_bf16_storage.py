@@ -369,9 +369,9 @@ def test_merger_stencils(dev, li):
         call("sv_stencil3_fwd", ptr(xd), cin_mem, cin_mem, groups, ptr(D(wp, dev)), 1, ptr(D(bias, dev)), ptr(y), 12, 0, 9, None, 0, ptr(stats),
              I, Dg, Dg, Dg)
         cin = 36 if li == 4 else 9
-        dw = ops.fzeros(9, cin, 27, device=dev)
-        call("sv_stencil3_wgrad", ptr(xd), cin_mem, cin_mem, groups, ptr(A(dy)), 12, 12, ptr(dw), 9, cin, 12 if li == 4 else 16, 9, I, Dg, Dg, Dg)
-        return dict(y=y, stats=stats.sum(0).float(), dw=dw)
+        dw, db = ops.fzeros(9, cin, 27, device=dev), ops.fzeros(9, device=dev)
+        call("sv_stencil3_wgrad", ptr(xd), cin_mem, cin_mem, groups, ptr(A(dy)), 12, 12, ptr(dw), ptr(db), 9, cin, 12 if li == 4 else 16, 9, I, Dg, Dg, Dg)
+        return dict(y=y, stats=stats.sum(0).float(), dw=dw, db=db)
 
     both(run, dev)
 
