@@ -107,9 +107,12 @@ int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups, const void
                     const float* bias, void* out, int ldc, int col_off, int cout, const void* residual, int ldr,
                     double* stats, int I, int D, int H, int W, int act_dtype, void* stream);
 /* dw[co][ci][27] += sum_vox dy[vox][co] * x[vox + tap][c]; memory channel c maps to ci = (c / c_stride)*c_valid + c % c_stride;
- * optional dbias[co] += sum_vox dy[vox][co] */
+ * optional dbias[co] += sum_vox dy[vox][co].  workspace: NULL (every workgroup adds into dw directly) or
+ * sv_stencil3_wgrad_workspace_floats(cout, cin) floats, ZERO on entry: partial sums are spread over slot images and
+ * folded into dw by a second small kernel (removes the ~1000-way atomic contention per weight) */
+size_t sv_stencil3_wgrad_workspace_floats(int cout, int cin);
 int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int groups, const void* dy, int lddy, int cout_load,
-                      float* dw, float* dbias, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W, int act_dtype,
+                      float* dw, float* dbias, float* workspace, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W, int act_dtype,
                       void* stream);
 /* dst[a][t][b] (b padded with zeros to pad_to) from the fp32 parameter src[a][b][t] (swap=0), or dst[b][t][a..pad_to] (swap=1);
  * dst elements are out_dtype (SV_F32 / SV_BF16) */

@@ -200,12 +200,24 @@ template <typename AT>
 struct StencilWArgsT {
   const AT* x; int ldx; int cin_load;        // gathered operand (conv input), memory channels = 16*G (zero-padded)
   const AT* dy; int lddy; int cout_load;     // anchor operand (output gradient), <= 16 memory channels
-  float* dw;                                 // native [cout][cin][27], accumulated with atomics
+  float* dw;                                 // native [cout][cin][27], accumulated with atomics (directly, or through `ws`)
+  float* ws;                                 // optional [WG_SLOTS][cout*cin*27] zeroed slot images folded into dw by a second kernel
   float* dbias;                              // optional [cout]: += sum_vox dy[vox][co]
   int cout, cin;                             // real channel counts
   int c_stride, c_valid;                     // memory channel c -> real channel (c / c_stride) * c_valid + c % c_stride, valid if c % c_stride < c_valid
   int I, D, H, W, ntiles;
 };
+
+constexpr int WG_SLOTS = 16;   // workgroups spread their partial sums over this many images (1024 workgroups on one image
+                               // serialise ~1000 atomics per weight; measured 450 us vs the ~30 us the contraction needs)
+__global__ __launch_bounds__(256) void stencil_wgrad_fold_kernel(const float* __restrict__ ws, float* __restrict__ dw, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+#pragma unroll
+  for (int sl = 0; sl < WG_SLOTS; ++sl) a += ws[(size_t)sl * n + i];
+  dw[i] += a;
+}
 
 template <int G, typename AT>
 __global__ __launch_bounds__(256) void stencil3_wgrad_kernel(const StencilWArgsT<AT> p) {
@@ -301,6 +313,7 @@ __global__ __launch_bounds__(256) void stencil3_wgrad_kernel(const StencilWArgsT
     }
   }
   // C element: row = lg*4 + j -> co, col = lr -> memory channel 16*gg + lr
+  float* dst = p.ws ? p.ws + (size_t)(blockIdx.x % WG_SLOTS) * p.cout * p.cin * 27 : p.dw;
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     if (i < ntap) {
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(256) void stencil3_wgrad_kernel(const StencilWArgsT
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int co = lg * 4 + j;
-            if (co < p.cout) atomicAdd(p.dw + ((size_t)co * p.cin + ci) * 27 + tap, acc[i][gg][j]);
+            if (co < p.cout) atomicAdd(dst + ((size_t)co * p.cin + ci) * 27 + tap, acc[i][gg][j]);
           }
         }
       }
@@ -362,9 +375,11 @@ extern "C" int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups,
   return check_launch("sv_stencil3_fwd");
 }
 
+extern "C" size_t sv_stencil3_wgrad_workspace_floats(int cout, int cin) { return (size_t)WG_SLOTS * cout * cin * 27; }
+
 extern "C" int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int groups, const void* dy, int lddy, int cout_load,
-                                 float* dw, float* dbias, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W,
-                                 int act_dtype, void* stream) {
+                                 float* dw, float* dbias, float* workspace, int cout, int cin, int c_stride, int c_valid, int I, int D, int H,
+                                 int W, int act_dtype, void* stream) {
   SV_REQUIRE(x && dy && dw, "stencil3_wgrad: null argument");
   SV_REQUIRE_ACT(act_dtype);
   if (int rc = stencil_check(I, D, H, W)) return rc;
@@ -378,9 +393,10 @@ extern "C" int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int group
   const int blocks = ntiles < resident ? ntiles : resident;
   hipStream_t s = (hipStream_t)stream;
   SV_DISPATCH_ACT(act_dtype,
-    StencilWArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, static_cast<const AT*>(dy), lddy, cout_load, dw, dbias, cout, cin, c_stride, c_valid,
+    StencilWArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, static_cast<const AT*>(dy), lddy, cout_load, dw, workspace, dbias, cout, cin, c_stride, c_valid,
                         I, D, H, W, ntiles};
     if (groups == 1) hipLaunchKernelGGL((stencil3_wgrad_kernel<1, AT>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((stencil3_wgrad_kernel<3, AT>), dim3(blocks), dim3(256), 0, s, a););
+  if (workspace) hipLaunchKernelGGL(stencil_wgrad_fold_kernel, dim3(cdiv(cout * cin * 27, 256)), dim3(256), 0, s, workspace, dw, cout * cin * 27);
   return check_launch("sv_stencil3_wgrad");
 }

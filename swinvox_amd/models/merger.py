@@ -93,8 +93,9 @@ class Merger(HipModule):
     def _conv_wgrad(self, li, dy, lddy, x, ldx, grads):
         conv, I = self._layer(li)[0], dy.shape[0] // VOX
         if ops.get_math() == "bf16":
+            ws = ops.zeros_f64(8 * conv.out_channels * conv.in_channels * 27, dy.device)   # 16 slot images of floats, zero on entry
             call("sv_stencil3_wgrad", ptr(x), ldx, 48 if li == 4 else 12, 3 if li == 4 else 1, ptr(dy), lddy, lddy if lddy <= 12 else 12,
-                 ptr(grads[conv.weight]), ptr(grads[conv.bias]), conv.out_channels, conv.in_channels, 12 if li == 4 else 16, 9, I, 32, 32, 32)
+                 ptr(grads[conv.weight]), ptr(grads[conv.bias]), ptr(ws), conv.out_channels, conv.in_channels, 12 if li == 4 else 16, 9, I, 32, 32, 32)
         elif li == 4:
             dw5p = fzeros(9, 48, 27, like=dy)
             self._s5.wgrad(dy, x, I, G, dw5p, lddy=lddy, ldx=ldx)

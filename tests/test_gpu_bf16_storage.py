@@ -370,7 +370,8 @@ def test_merger_stencils(dev, li):
              I, Dg, Dg, Dg)
         cin = 36 if li == 4 else 9
         dw, db = ops.fzeros(9, cin, 27, device=dev), ops.fzeros(9, device=dev)
-        call("sv_stencil3_wgrad", ptr(xd), cin_mem, cin_mem, groups, ptr(A(dy)), 12, 12, ptr(dw), ptr(db), 9, cin, 12 if li == 4 else 16, 9, I, Dg, Dg, Dg)
+        ws = ops.fzeros(int(hip.load().sv_stencil3_wgrad_workspace_floats(9, cin)), device=dev)
+        call("sv_stencil3_wgrad", ptr(xd), cin_mem, cin_mem, groups, ptr(A(dy)), 12, 12, ptr(dw), ptr(db), ptr(ws), 9, cin, 12 if li == 4 else 16, 9, I, Dg, Dg, Dg)
         return dict(y=y, stats=stats.sum(0).float(), dw=dw, db=db)
 
     both(run, dev)

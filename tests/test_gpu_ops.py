@@ -528,5 +528,5 @@ def test_stencil3_fwd_dgrad_wgrad(dev, cin, cout, groups):
     assert rel((dx.cpu() - base)[:, cols], cl(x.grad).reshape(M, cin)) < 2e-5
     # weight gradient (bf16 operands, fp32 atomics)
     dw = ops.zeros(cout, cin, 3, 3, 3, device=dev)
-    call("sv_stencil3_wgrad", ptr(xd), ld, ld, groups, ptr(dyd), 12, 12, ptr(dw), None, cout, cin, 16 if groups == 1 else 12, 9, n, D, D, D)
+    call("sv_stencil3_wgrad", ptr(xd), ld, ld, groups, ptr(dyd), 12, 12, ptr(dw), None, None, cout, cin, 16 if groups == 1 else 12, 9, n, D, D, D)
     assert rel(dw, w.grad) < 2e-4
