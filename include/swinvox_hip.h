@@ -175,7 +175,10 @@ int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const void* x, i
  * ---------------------------------------------------------------------------------------------- */
 int sv_window_attention_fwd(const void* qkv, const float* table, void* out, int I, int H, int W, int C, int heads,
                             int shift, int math, int act_dtype, void* stream);
-int sv_window_attention_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable,
+/* workspace: NULL, or sv_window_attention_bwd_workspace_floats(heads) floats, ZERO on entry (slot images of dtable, folded
+ * by a second small kernel; used by the bf16-MFMA kernels) */
+size_t sv_window_attention_bwd_workspace_floats(int heads);
+int sv_window_attention_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable, float* workspace,
                             int I, int H, int W, int C, int heads, int shift, int math, int act_dtype, void* stream);
 int sv_cross_view_attention_fwd(const void* qkv, void* out, int B, int V, int P, int R, int heads, int act_dtype, void* stream);
 int sv_cross_view_attention_bwd(const void* qkv, const void* dout, void* dqkv, int B, int V, int P, int R, int heads,

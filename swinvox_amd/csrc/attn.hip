@@ -738,6 +738,291 @@ __global__ __launch_bounds__(256) void cva_attn_bwd_kernel(const CvaArgsT<AT> p)
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Workgroup-per-window kernels (bf16 MFMA): the 4 waves of a workgroup split the 64 (49 used) query rows of ONE
+// (window, head) task - 16 rows each - and the key rows of the transposed products.  Per-wave state is a 16 x 64 score
+// strip (16 accumulator registers) instead of the whole 64 x 64 matrix, so 4-6 workgroups fit a CU (LDS 25 / 41 KB) and
+// every SIMD holds 4+ waves to hide LDS / HBM latency (the wave-per-window kernels above run 1 wave per SIMD at 256 VGPRs
+// and are kept for exact-fp32 MFMA).  A workgroup walks `tasks_per_wave` windows of one head; the relative-position-bias
+// gradient is accumulated in REGISTERS across its windows (the (query, key) -> table index map is the same for all) and
+// reaches LDS / HBM once per workgroup.
+// ------------------------------------------------------------------------------------------------
+// bias + mask + softmax over the keys for ONE 16-row strip (query rows mt*16 + lg*4 + j, keys nt*16 + lr).
+// The relative-position bias of this lane's 16 (query, key) slots is the same for every window of a head: it is gathered
+// once per workgroup into registers (strip_bias); the shifted-window mask only exists in the last window row / column.
+__device__ __forceinline__ void strip_bias(float (&bias)[4][4], const float* bt, int lane, int mt) {
+  const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int key = nt * 16 + lr, ky = key / 7, kx = key - ky * 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = mt * 16 + lg * 4 + j, qy = q / 7, qx = q - qy * 7;
+      bias[nt][j] = key >= WT ? -1.0e30f : (q < WT ? bt[(qy - ky + 6) * 13 + (qx - kx + 6)] : 0.f);   // key padding: excluded
+    }
+  }
+}
+__device__ __forceinline__ void bias_mask_softmax_strip(f32x4 (&s)[4], const float (&bias)[4][4], const TokMap& tm, int lane, bool masked, int mt) {
+  const int lr = lane & 15, lg = lane >> 4;
+  if (masked) {   // a window touching the rolled seam: tokens of different regions must not attend to each other
+    int kreg[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { const int key = nt * 16 + lr; kreg[nt] = key < WT ? tm.region(key) : 0; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = mt * 16 + lg * 4 + j;
+      const int qreg = q < WT ? tm.region(q) : 0;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        if (q < WT && nt * 16 + lr < WT && qreg != kreg[nt]) s[nt][j] += -100.0f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const float v = bias[nt][j] <= -1.0e29f ? -1.0e30f : s[nt][j] + bias[nt][j];
+      s[nt][j] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = group16_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { const float e = __expf(s[nt][j] - mx); s[nt][j] = e; sum += e; }
+    const float inv = 1.f / group16_sum(sum);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) s[nt][j] *= inv;
+  }
+}
+
+// cooperative (256 threads) load of one [49(64) x 32] head slice into a bf16 LDS tile [64][LDQ_H]; rows >= 49 zeroed
+template <typename AT>
+__device__ __forceinline__ void load_tile_wg(__bf16* dst, const AT* src, int ld, int col, const TokMap& tm, int tid, float mul) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = (tid >> 3) + 32 * it, ch = (tid & 7) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < WT) v = ld4f(src + (size_t)tm.row(r) * ld + col + ch);
+    bf16x4 b;
+    b[0] = (__bf16)(v.x * mul); b[1] = (__bf16)(v.y * mul); b[2] = (__bf16)(v.z * mul); b[3] = (__bf16)(v.w * mul);
+    *reinterpret_cast<bf16x4*>(dst + r * LDQ_H + ch) = b;
+  }
+}
+
+__device__ __forceinline__ TokMap task_map(long long task, int nW, int nWx, int H, int W, int shift) {
+  TokMap tm;
+  tm.img = (int)(task / nW); const int win = (int)(task - (long long)tm.img * nW);
+  tm.wy = win / nWx; tm.wx = win - tm.wy * nWx; tm.H = H; tm.W = W; tm.shift = shift;
+  return tm;
+}
+
+template <typename AT>
+__global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<AT> p) {
+  __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * LDQ_H], Ks[64 * LDQ_H], Vt[HD * LDP_H], Ps[64 * LDP_H];
+  __shared__ float bt[176];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int head = blockIdx.y;
+  const int nWx = p.W / 7, nW = (p.H / 7) * nWx;
+  const int ld = 3 * p.C, colq = head * HD;
+  for (int i = tid; i < 169; i += 256) bt[i] = p.table[i * p.heads + head];
+  for (int i = tid; i < HD * LDP_H; i += 256) Vt[i] = (__bf16)0.f;      // key columns >= 49 stay zero
+  __syncthreads();
+  float bias[4][4];
+  strip_bias(bias, bt, lane, wave);
+  const long long task0 = (long long)blockIdx.x * p.tasks_per_wave;
+  for (int tt = 0; tt < p.tasks_per_wave; ++tt) {
+    const long long task = task0 + tt;
+    if (task >= p.ntasks) break;                                         // uniform over the workgroup
+    const TokMap tm = task_map(task, nW, nWx, p.H, p.W, p.shift);
+    __syncthreads();                                                     // previous window's tiles are consumed
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int r = (tid >> 3) + 32 * it, ch = (tid & 7) * 4;
+      float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;
+      if (r < WT) {
+        const AT* src = p.qkv + (size_t)tm.row(r) * ld + colq + ch;
+        q4 = ld4f(src); k4 = ld4f(src + p.C); v4 = ld4f(src + 2 * p.C);
+      }
+      bf16x4 qb, kb;
+      qb[0] = (__bf16)(q4.x * p.scale); qb[1] = (__bf16)(q4.y * p.scale); qb[2] = (__bf16)(q4.z * p.scale); qb[3] = (__bf16)(q4.w * p.scale);
+      kb[0] = (__bf16)k4.x; kb[1] = (__bf16)k4.y; kb[2] = (__bf16)k4.z; kb[3] = (__bf16)k4.w;
+      *reinterpret_cast<bf16x4*>(Qs + r * LDQ_H + ch) = qb;
+      *reinterpret_cast<bf16x4*>(Ks + r * LDQ_H + ch) = kb;
+      if (r < WT) {
+        Vt[(ch + 0) * LDP_H + r] = (__bf16)v4.x; Vt[(ch + 1) * LDP_H + r] = (__bf16)v4.y;
+        Vt[(ch + 2) * LDP_H + r] = (__bf16)v4.z; Vt[(ch + 3) * LDP_H + r] = (__bf16)v4.w;
+      }
+    }
+    __syncthreads();
+    f32x4 s[4];
+    {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + (wave * 16 + lr) * LDQ_H + lg * 8);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Ks + (nt * 16 + lr) * LDQ_H + lg * 8);
+        s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+    }
+    bias_mask_softmax_strip(s, bias, tm, lane, p.shift > 0 && (tm.wy == p.H / 7 - 1 || tm.wx == nWx - 1), wave);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Ps[(wave * 16 + lg * 4 + j) * LDP_H + nt * 16 + lr] = (__bf16)s[nt][j];
+    __syncthreads();
+    f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ps + (wave * 16 + lr) * LDP_H + ks * 32 + lg * 8);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Vt + (nt * 16 + lr) * LDP_H + ks * 32 + lg * 8);
+        o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, o[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = wave * 16 + lg * 4 + j;
+      if (q < WT) {
+        AT* dst = p.out + (size_t)tm.row(q) * p.C + colq;
+        stf(dst + lr, o[0][j]);
+        stf(dst + 16 + lr, o[1][j]);
+      }
+    }
+  }
+}
+
+constexpr int ATTN_DT_SLOTS = 16;   // slot images of the relative-position-bias gradient (see sv_window_attention_bwd)
+
+template <typename AT>
+__global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<AT> p, float* __restrict__ dt_ws) {
+  __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * LDQ_H], Ks[64 * LDQ_H], Vs[64 * LDQ_H], Ds[64 * LDQ_H];
+  __shared__ __attribute__((aligned(16))) __bf16 Ps[64 * LDP_H], Ss[64 * LDP_H];   // P and dS, [query][key]
+  __shared__ float bt[176], dbt[176];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int head = blockIdx.y;
+  const int nWx = p.W / 7, nW = (p.H / 7) * nWx;
+  const int ld = 3 * p.C, colq = head * HD;
+  for (int i = tid; i < 176; i += 256) { bt[i] = i < 169 ? p.table[i * p.heads + head] : 0.f; dbt[i] = 0.f; }
+  __syncthreads();
+  float bias[4][4];
+  strip_bias(bias, bt, lane, wave);
+  f32x4 dsum[4];                                   // sum over this workgroup's windows of dS at this lane's (query, key) slots
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) dsum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const long long task0 = (long long)blockIdx.x * p.tasks_per_wave;
+  for (int tt = 0; tt < p.tasks_per_wave; ++tt) {
+    const long long task = task0 + tt;
+    if (task >= p.ntasks) break;
+    const TokMap tm = task_map(task, nW, nWx, p.H, p.W, p.shift);
+    __syncthreads();
+    load_tile_wg(Qs, p.qkv, ld, colq, tm, tid, p.scale);
+    load_tile_wg(Ks, p.qkv, ld, p.C + colq, tm, tid, 1.f);
+    load_tile_wg(Vs, p.qkv, ld, 2 * p.C + colq, tm, tid, 1.f);
+    load_tile_wg(Ds, p.dout, p.C, colq, tm, tid, 1.f);
+    __syncthreads();
+    // ---- this wave's 16 query rows: S = (scale Q) K^T, dP = dO V^T, P = softmax, dS = P o (dP - rowsum(dP o P))
+    f32x4 s[4], dp[4];
+    {
+      const int off = (wave * 16 + lr) * LDQ_H + lg * 8;
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + off), c = *reinterpret_cast<const bf16x8*>(Ds + off);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int offb = (nt * 16 + lr) * LDQ_H + lg * 8;
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Ks + offb), d = *reinterpret_cast<const bf16x8*>(Vs + offb);
+        s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, d, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+    }
+    bias_mask_softmax_strip(s, bias, tm, lane, p.shift > 0 && (tm.wy == p.H / 7 - 1 || tm.wx == nWx - 1), wave);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float r = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) r += dp[nt][j] * s[nt][j];
+      r = group16_sum(r);
+      const bool qok = wave * 16 + lg * 4 + j < WT;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float dsv = s[nt][j] * (dp[nt][j] - r);
+        dp[nt][j] = dsv;
+        if (qok && nt * 16 + lr < WT) dsum[nt][j] += dsv;
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o = (wave * 16 + lg * 4 + j) * LDP_H + nt * 16 + lr;
+        Ps[o] = (__bf16)s[nt][j]; Ss[o] = (__bf16)dp[nt][j];
+      }
+    __syncthreads();
+    // ---- rows of this wave: keys 16w.. for dV = P^T dO and dK = dS^T (scale Q); queries 16w.. for dQ = scale dS K
+    f32x4 av[2], ak[2], aq[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) { av[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ak[nt] = av[nt]; aq[nt] = av[nt]; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 pT = tr_frag(Ps, LDP_H, ks * 32, wave * 16, lane);        // A[key][q]
+      const bf16x8 sT = tr_frag(Ss, LDP_H, ks * 32, wave * 16, lane);        // A[key][q]
+      const bf16x8 sR = *reinterpret_cast<const bf16x8*>(Ss + (wave * 16 + lr) * LDP_H + ks * 32 + lg * 8);   // A[q][key]
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const bf16x8 bd = tr_frag(Ds, LDQ_H, ks * 32, nt * 16, lane);        // dO[q][d]
+        const bf16x8 bq = tr_frag(Qs, LDQ_H, ks * 32, nt * 16, lane);        // (scale Q)[q][d]
+        const bf16x8 bk = tr_frag(Ks, LDQ_H, ks * 32, nt * 16, lane);        // K[key][d]
+        av[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pT, bd, av[nt], 0, 0, 0);
+        ak[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sT, bq, ak[nt], 0, 0, 0);
+        aq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sR, bk, aq[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = wave * 16 + lg * 4 + j;       // a key row for dV / dK, a query row for dQ
+      if (t < WT) {
+        AT* dst = p.dqkv + (size_t)tm.row(t) * ld + colq;
+        stf(dst + lr, aq[0][j] * p.scale); stf(dst + 16 + lr, aq[1][j] * p.scale);
+        stf(dst + p.C + lr, ak[0][j]); stf(dst + p.C + 16 + lr, ak[1][j]);
+        stf(dst + 2 * p.C + lr, av[0][j]); stf(dst + 2 * p.C + 16 + lr, av[1][j]);
+      }
+    }
+  }
+  // ---- relative-position-bias gradient: registers -> LDS (once per workgroup) -> one atomic per table entry
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = wave * 16 + lg * 4 + j;
+    if (q < WT) {
+      const int qy = q / 7, qx = q - qy * 7;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int key = nt * 16 + lr;
+        if (key < WT) {
+          const int ky = key / 7, kx = key - ky * 7;
+          atomicAdd(dbt + (qy - ky + 6) * 13 + (qx - kx + 6), dsum[nt][j]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* dst = dt_ws ? dt_ws + (size_t)(blockIdx.x % ATTN_DT_SLOTS) * 169 * p.heads : p.dtable;
+  for (int i = tid; i < 169; i += 256) {
+    const float v = dbt[i];
+    if (v != 0.f) atomicAdd(dst + i * p.heads + head, v);
+  }
+}
+__global__ __launch_bounds__(256) void attn_dtable_fold_kernel(const float* __restrict__ ws, float* __restrict__ dtable, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+#pragma unroll
+  for (int sl = 0; sl < ATTN_DT_SLOTS; ++sl) a += ws[(size_t)sl * n + i];
+  dtable[i] += a;
+}
+
 }  // namespace sv
 
 using namespace sv;
@@ -770,37 +1055,55 @@ extern "C" int sv_window_attention_fwd(const void* qkv, const float* table, void
   if (int rc = win_check(qkv, table, I, H, W, C, heads, shift, math, act_dtype)) return rc;
   SV_REQUIRE(out, "window_attention_fwd: null out");
   const int ntasks = I * (H / 7) * (W / 7);
-  dim3 grid(cdiv(ntasks, 4), heads);
   hipStream_t s = (hipStream_t)stream;
-  if (act_dtype == SV_BF16)
-    hipLaunchKernelGGL((win_attn_fwd_kernel<true, __bf16>), grid, dim3(256), 0, s, win_args<__bf16>(qkv, table, out, nullptr, nullptr, nullptr, I, H, W, C, heads, shift));
-  else if (math == SV_MATH_BF16)
-    hipLaunchKernelGGL((win_attn_fwd_kernel<true, float>), grid, dim3(256), 0, s, win_args<float>(qkv, table, out, nullptr, nullptr, nullptr, I, H, W, C, heads, shift));
-  else
+  if (math == SV_MATH_BF16) {   // workgroup per window; a workgroup walks tpb windows of one head (>= ~2048 workgroups in the grid)
+    int tpb = (int)((long long)ntasks * heads / 2048); if (tpb < 1) tpb = 1; if (tpb > 8) tpb = 8;
+    dim3 grid(cdiv(ntasks, tpb), heads);
+    if (act_dtype == SV_BF16) {
+      WinArgsT<__bf16> a = win_args<__bf16>(qkv, table, out, nullptr, nullptr, nullptr, I, H, W, C, heads, shift);
+      a.tasks_per_wave = tpb;
+      hipLaunchKernelGGL(win_attn_fwd_wg_kernel<__bf16>, grid, dim3(256), 0, s, a);
+    } else {
+      WinArgs a = win_args<float>(qkv, table, out, nullptr, nullptr, nullptr, I, H, W, C, heads, shift);
+      a.tasks_per_wave = tpb;
+      hipLaunchKernelGGL(win_attn_fwd_wg_kernel<float>, grid, dim3(256), 0, s, a);
+    }
+  } else {
+    dim3 grid(cdiv(ntasks, 4), heads);
     hipLaunchKernelGGL((win_attn_fwd_kernel<false, float>), grid, dim3(256), 0, s, win_args<float>(qkv, table, out, nullptr, nullptr, nullptr, I, H, W, C, heads, shift));
+  }
   return check_launch("sv_window_attention_fwd");
 }
 
-extern "C" int sv_window_attention_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable,
+extern "C" size_t sv_window_attention_bwd_workspace_floats(int heads) { return (size_t)ATTN_DT_SLOTS * 169 * heads; }
+
+extern "C" int sv_window_attention_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable, float* workspace,
                                        int I, int H, int W, int C, int heads, int shift, int math, int act_dtype, void* stream) {
   if (int rc = win_check(qkv, table, I, H, W, C, heads, shift, math, act_dtype)) return rc;
   SV_REQUIRE(dout && dqkv && dtable && ((uintptr_t)dout & 15) == 0, "window_attention_bwd: null/unaligned argument");
   const int ntasks = I * (H / 7) * (W / 7);
-  const int wpb = math == SV_MATH_BF16 ? 4 : 2;   // waves per workgroup
-  // several windows per wave (same head) so the bias gradient is reduced on chip; keep >= ~1024 waves in the grid
-  int tpw = 1;
-  while (tpw < 8 && (long long)ntasks * heads / (tpw * 2) > 2048) tpw *= 2;
-  dim3 grid(cdiv(ntasks, wpb * tpw), heads);
   hipStream_t s = (hipStream_t)stream;
-  if (act_dtype == SV_BF16) {
-    WinArgsT<__bf16> a = win_args<__bf16>(qkv, table, nullptr, dout, dqkv, dtable, I, H, W, C, heads, shift);
-    a.tasks_per_wave = tpw;
-    hipLaunchKernelGGL(win_attn_bwd_bf16_kernel<__bf16>, grid, dim3(256), 0, s, a);
+  if (math == SV_MATH_BF16) {   // workgroup per window, tpb windows of one head per workgroup
+    int tpb = (int)((long long)ntasks * heads / 2048); if (tpb < 1) tpb = 1; if (tpb > 8) tpb = 8;
+    dim3 grid(cdiv(ntasks, tpb), heads);
+    if (act_dtype == SV_BF16) {
+      WinArgsT<__bf16> a = win_args<__bf16>(qkv, table, nullptr, dout, dqkv, dtable, I, H, W, C, heads, shift);
+      a.tasks_per_wave = tpb;
+      hipLaunchKernelGGL(win_attn_bwd_wg_kernel<__bf16>, grid, dim3(256), 0, s, a, workspace);
+    } else {
+      WinArgs a = win_args<float>(qkv, table, nullptr, dout, dqkv, dtable, I, H, W, C, heads, shift);
+      a.tasks_per_wave = tpb;
+      hipLaunchKernelGGL(win_attn_bwd_wg_kernel<float>, grid, dim3(256), 0, s, a, workspace);
+    }
+    if (workspace) hipLaunchKernelGGL(attn_dtable_fold_kernel, dim3(cdiv(169 * heads, 256)), dim3(256), 0, s, workspace, dtable, 169 * heads);
   } else {
+    // exact-fp32 MFMA: wave per window, several windows per wave (same head) so the bias gradient is reduced on chip
+    int tpw = 1;
+    while (tpw < 8 && (long long)ntasks * heads / (tpw * 2) > 2048) tpw *= 2;
+    dim3 grid(cdiv(ntasks, 2 * tpw), heads);
     WinArgs a = win_args<float>(qkv, table, nullptr, dout, dqkv, dtable, I, H, W, C, heads, shift);
     a.tasks_per_wave = tpw;
-    if (math == SV_MATH_BF16) hipLaunchKernelGGL(win_attn_bwd_bf16_kernel<float>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(win_attn_bwd_kernel, grid, dim3(128), 0, s, a);
+    hipLaunchKernelGGL(win_attn_bwd_kernel, grid, dim3(128), 0, s, a);
   }
   return check_launch("sv_window_attention_bwd");
 }

@@ -76,7 +76,8 @@ _PROTOS = {
     "sv_scale_shift_act": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _F]),
     "sv_bn_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _L, _I, _I, _F, _I, _P, _I, _P, _I, _P, _P, _P]),
     "sv_window_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
-    "sv_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
+    "sv_window_attention_bwd_workspace_floats": (C.c_size_t, None, [_I]),
+    "sv_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "sv_cross_view_attention_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I]),
     "sv_cross_view_attention_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
     "sv_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _L]),

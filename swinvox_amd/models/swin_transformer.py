@@ -191,8 +191,9 @@ def block_backward(blk: SwinBlock, ctx, dx2, grads):
     datt = empty(M, Cd, like=x)
     ops.linear_dgrad(dbr, M, blk.s_proj, blk.s_proj.pack_dgrad(blk.attn.proj.weight), datt)
     dqkv = empty(M, 3 * Cd, like=x)
+    ws = ops.zeros_f64(8 * 169 * blk.heads, x.device)    # sv_window_attention_bwd_workspace_floats(heads) floats, zero on entry
     call("sv_window_attention_bwd", ptr(qkv), ptr(blk.attn.relative_position_bias_table), ptr(datt), ptr(dqkv),
-         ptr(grads[blk.attn.relative_position_bias_table]), I, H, W, Cd, blk.heads, blk.shift, ops._STATE["math"])
+         ptr(grads[blk.attn.relative_position_bias_table]), ptr(ws), I, H, W, Cd, blk.heads, blk.shift, ops._STATE["math"])
     ops.linear_wgrad(dqkv, ln1, M, blk.s_qkv, grads[blk.attn.qkv.weight], grads[blk.attn.qkv.bias])
     dln1 = empty(M, Cd, like=x)
     ops.linear_dgrad(dqkv, M, blk.s_qkv, blk.s_qkv.pack_dgrad(blk.attn.qkv.weight), dln1)

@@ -228,7 +228,7 @@ def test_window_attention(dev, shift):
         call("sv_window_attention_fwd", ptr(qd), ptr(D(table, dev)), ptr(out), I, H, H, Cd, heads, shift, hip.MATH_BF16)
         dqkv = ops.empty(I * H * H, 3 * Cd, device=dev)
         dt = ops.fzeros(169, heads, device=dev)
-        call("sv_window_attention_bwd", ptr(qd), ptr(D(table, dev)), ptr(A(dout)), ptr(dqkv), ptr(dt), I, H, H, Cd, heads, shift, hip.MATH_BF16)
+        call("sv_window_attention_bwd", ptr(qd), ptr(D(table, dev)), ptr(A(dout)), ptr(dqkv), ptr(dt), None, I, H, H, Cd, heads, shift, hip.MATH_BF16)
         return dict(out=out, dqkv=dqkv, dtable=dt)
 
     both(run, dev)

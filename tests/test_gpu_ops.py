@@ -330,10 +330,11 @@ def test_window_attention(dev, H, heads, shift):
     assert rel(out16, ref) < 2e-2
     dqkv, dt = ops.empty(I * H * H, 3 * Cd, device=dev), ops.zeros(169, heads, device=dev)
     dod = do.to(dev)
-    call("sv_window_attention_bwd", ptr(qd), ptr(td), ptr(dod), ptr(dqkv), ptr(dt), I, H, H, Cd, heads, shift, hip.MATH_F32)
+    call("sv_window_attention_bwd", ptr(qd), ptr(td), ptr(dod), ptr(dqkv), ptr(dt), None, I, H, H, Cd, heads, shift, hip.MATH_F32)
     assert rel(dqkv, qkv.grad) < TOL and rel(dt, table.grad) < TOL
     dqkv16, dt16 = ops.empty(I * H * H, 3 * Cd, device=dev), ops.zeros(169, heads, device=dev)
-    call("sv_window_attention_bwd", ptr(qd), ptr(td), ptr(dod), ptr(dqkv16), ptr(dt16), I, H, H, Cd, heads, shift, hip.MATH_BF16)
+    ws16 = ops.fzeros(int(hip.load().sv_window_attention_bwd_workspace_floats(heads)), device=dev)   # slot-spread dtable partial sums
+    call("sv_window_attention_bwd", ptr(qd), ptr(td), ptr(dod), ptr(dqkv16), ptr(dt16), ptr(ws16), I, H, H, Cd, heads, shift, hip.MATH_BF16)
     assert rel(dqkv16, qkv.grad) < 3e-2 and rel(dt16, table.grad) < 3e-2
 
 
