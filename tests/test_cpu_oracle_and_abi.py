@@ -125,6 +125,40 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert exported == declared
 
 
+def test_ctypes_prototypes_match_the_header():
+    """Every prototype of include/swinvox_hip.h against the ctypes argument list the host side binds (count and class of
+    every argument: pointer / int / long long / float / uint32), and the workspace-size helpers against the host constants
+    (pure host functions, no GPU)."""
+    from swinvox_amd import ops
+    hdr = open(os.path.join(ROOT, "include", "swinvox_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = re.findall(r"\b(?:int|size_t)\s+(sv_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)
+    assert len(protos) >= 50
+
+    def code(a):
+        a = a.strip()
+        if a in ("void", ""):
+            return None
+        if "*" in a:
+            return "P"
+        for key, c in (("long long", "L"), ("uint32_t", "U"), ("float", "F"), ("int", "I")):
+            if key in a:
+                return c
+        raise AssertionError(a)
+
+    cmap = {ctypes.c_void_p: "P", ctypes.c_int: "I", ctypes.c_longlong: "L", ctypes.c_float: "F", ctypes.c_uint32: "U"}
+    for name, args in protos:
+        want = [c for c in (code(a) for a in args.split(",")) if c]
+        got = [cmap.get(t, "P") for t in hip._argtypes(name)]
+        assert want == got, (name, "".join(want), "".join(got))
+    lib = hip.load()
+    assert lib.sv_bn_bwd_workspace_doubles(64) == (ops.BN_BWD_SLOTS + 1) * 2 * 64 + 2
+    assert lib.sv_layernorm_bwd_workspace_floats(96) == 2 * (ops.LN_BWD_SLOTS * 96 + 1)
+    assert lib.sv_stencil3_wgrad_workspace_floats(9, 36) == 2 * (8 * 9 * 36 * 27)
+    assert lib.sv_window_attention_bwd_workspace_floats(3) == 2 * (8 * 169 * 3)
+    assert lib.sv_pack_weights_block_elems() > 0 and ctypes.sizeof(hip.PackDesc) == 48
+
+
 def test_product_fails_loudly_without_gpu_or_library(monkeypatch):
     m = Refiner(S.default_cfg())
     with pytest.raises(RuntimeError, match="GPU"):
