@@ -70,10 +70,15 @@ class _ModuleFn(torch.autograd.Function):
         ops.set_pack_cache(mod.__dict__.setdefault("_packs", ops.PackCache()))
         arena = mod.__dict__.setdefault("_arena_b", ops.ZeroArena())
         ops.set_arena(arena)
+        aw = ops.AsyncWgrad(grads.flat.device) if ops.overlap_enabled() else None
+        ops.set_async_wgrad(aw)
         try:
             arena.begin(douts[0].device if douts[0] is not None else grads.flat.device)
             d_inputs = mod._bwd(ctx.tape, grads, ctx.in_needs, *douts)
         finally:
+            ops.set_async_wgrad(None)
+            if aw is not None:
+                aw.join()                        # every parameter gradient is complete on the caller's stream
             arena.end()
             ops.set_pack_cache(None)
             ops.set_arena(None)

@@ -98,7 +98,7 @@ class Merger(HipModule):
                  ptr(grads[conv.weight]), ptr(grads[conv.bias]), ptr(ws), conv.out_channels, conv.in_channels, 12 if li == 4 else 16, 9, I, 32, 32, 32)
         elif li == 4:
             dw5p = fzeros(9, 48, 27, like=dy)
-            self._s5.wgrad(dy, x, I, G, dw5p, lddy=lddy, ldx=ldx)
+            self._s5.wgrad(dy, x, I, G, dw5p, lddy=lddy, ldx=ldx, async_ok=False)   # dw5p is read back right below
             grads[conv.weight].view(9, 36, 27).copy_(dw5p[:, self._cat_cols])
         else:
             self._spec(li).wgrad(dy, x, I, G, grads[conv.weight], lddy=lddy, ldx=ldx)

@@ -174,7 +174,8 @@ def block_backward(blk: SwinBlock, ctx, dx2, grads):
     if sc2 is not None:
         dbr = empty(M, Cd, like=x)
         call("sv_rowscale", ptr(dx2), ptr(sc2), ptr(dbr), M, Cd, H * W)
-    ops.linear_wgrad(dbr, h, M, blk.s_fc2, grads[blk.mlp.fc2.weight], grads[blk.mlp.fc2.bias])
+    # without a drop-path copy dbr IS dx2, which the LayerNorm backward below updates in place -> keep this one in order
+    ops.linear_wgrad(dbr, h, M, blk.s_fc2, grads[blk.mlp.fc2.weight], grads[blk.mlp.fc2.bias], async_ok=sc2 is not None)
     dh = empty(M, 4 * Cd, like=x)
     ops.linear_dgrad(dbr, M, blk.s_fc2, blk.s_fc2.pack_dgrad(blk.mlp.fc2.weight), dh, act_grad_src=hpre, act_grad_kind=ACT_GELU)
     ops.linear_wgrad(dh, ln2, M, blk.s_fc1, grads[blk.mlp.fc1.weight], grads[blk.mlp.fc1.bias])
@@ -187,7 +188,7 @@ def block_backward(blk: SwinBlock, ctx, dx2, grads):
     if sc1 is not None:
         dbr = empty(M, Cd, like=x)
         call("sv_rowscale", ptr(dx1), ptr(sc1), ptr(dbr), M, Cd, H * W)
-    ops.linear_wgrad(dbr, att, M, blk.s_proj, grads[blk.attn.proj.weight], grads[blk.attn.proj.bias])
+    ops.linear_wgrad(dbr, att, M, blk.s_proj, grads[blk.attn.proj.weight], grads[blk.attn.proj.bias], async_ok=sc1 is not None)
     datt = empty(M, Cd, like=x)
     ops.linear_dgrad(dbr, M, blk.s_proj, blk.s_proj.pack_dgrad(blk.attn.proj.weight), datt)
     dqkv = empty(M, 3 * Cd, like=x)

@@ -215,9 +215,23 @@ class ConvSpec:
                      C.byref(g), C.byref(e), _STATE["math"])
 
     # ---- weight gradient, accumulated into dw (native layout) ------------------------------------------
-    def wgrad(self, dy, x, n, in_grid, dw, *, lddy=None, ldx=None, db=None):
+    def wgrad(self, dy, x, n, in_grid, dw, *, lddy=None, ldx=None, db=None, async_ok=True):
         """dw += ...; for (non-transposed) conv / Linear layers db (bias gradient = column sums of dy) is folded into the
-        same kernel; transposed convs anchor on x, so their bias gradient needs the separate column-sum kernel."""
+        same kernel; transposed convs anchor on x, so their bias gradient needs the separate column-sum kernel.
+        Inside a module backward the launch goes to the weight-gradient stream (AsyncWgrad): nothing on the data-gradient
+        chain waits for a weight gradient.  async_ok=False keeps it on the caller's stream - required when dy or x is
+        modified in place afterwards."""
+        aw = _STATE.get("awg")
+        if aw is not None and async_ok:
+            cur = torch.cuda.current_stream()
+            aw.stream.wait_stream(cur)                 # dy and x are complete on the producing stream
+            aw.held.append((dy, x))                    # keep the operands alive (and unrecycled) until the join
+            with torch.cuda.stream(aw.stream):
+                self._wgrad(dy, x, n, in_grid, dw, lddy, ldx, db)
+            return
+        self._wgrad(dy, x, n, in_grid, dw, lddy, ldx, db)
+
+    def _wgrad(self, dy, x, n, in_grid, dw, lddy, ldx, db):
         og = self.out_grid(in_grid)
         if self.transposed:   # anchor = x (cin), gathered = dy (cout)
             g = self._geom(n, og, in_grid, self.cout_mem, self.cin, lddy or self.cout_mem)
@@ -341,6 +355,26 @@ def bn_tick_flush() -> None:
     _STATE["bn_tick"] = []
 
 
+class AsyncWgrad:
+    """Weight-gradient stream of one module backward (see ConvSpec.wgrad).  join() makes the caller's stream wait for every
+    weight gradient and releases the operand references."""
+    _streams = {}
+
+    def __init__(self, dev):
+        key = (dev.type, dev.index)
+        if key not in AsyncWgrad._streams:
+            AsyncWgrad._streams[key] = torch.cuda.Stream(device=dev)
+        self.stream, self.held = AsyncWgrad._streams[key], []
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.held.clear()
+
+
+def set_async_wgrad(aw) -> None:
+    _STATE["awg"] = aw
+
+
 _SIDE = {}
 
 
@@ -385,8 +419,8 @@ def linear_dgrad(dy, rows, spec: ConvSpec, w_t, dx, **epi):
     spec.dgrad(dy, rows, (1, 1, 1), w_t, dx, **epi)
 
 
-def linear_wgrad(dy, x, rows, spec: ConvSpec, dw, db=None):
-    spec.wgrad(dy, x, rows, (1, 1, 1), dw, db=db)
+def linear_wgrad(dy, x, rows, spec: ConvSpec, dw, db=None, async_ok=True):
+    spec.wgrad(dy, x, rows, (1, 1, 1), dw, db=db, async_ok=async_ok)
 
 
 # ---------------------------------------------------------------------------------------------------
