@@ -475,7 +475,9 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void wgrad_kerne
   typedef typename VecN<AT, VEC>::type AV;
   const AT* __restrict__ ANC = static_cast<const AT*>(p.anchor);
   const AT* __restrict__ GAT = static_cast<const AT*>(p.gathered);
-  constexpr int BK = Cfg<BF16>::BK, PAD = Cfg<BF16>::PAD;
+  // row stride = 8 banks mod 64 (bf16: +16 elements): the 4 rows a 16-lane group touches in one ds_read_b64_tr_b16 fall
+  // into disjoint 8-bank windows (with +8 elements rows q and q+1 overlap by 4 banks -> 2-way conflicts)
+  constexpr int BK = Cfg<BF16>::BK, PAD = BF16 ? 16 : Cfg<BF16>::PAD;
   constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT;
   constexpr int LDA = BM + PAD, LDB = BN + PAD;
   constexpr int NTHR = TL::NTHR;

@@ -553,6 +553,123 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const AT* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// narrow BatchNorm (C <= 16, every row stride a multiple of 4: the 9/12-channel merger tail): a thread owns ONE 4-channel
+// group of a row (g = tid & 3, 64 rows per workgroup pass), so a wave instruction moves 8/16-byte vectors that tile whole
+// rows (21 rows x 24 B with 9 channels) instead of one 2-byte element per lane in the generic scalar kernels, and the
+// per-channel constants of the group sit in registers.
+// ------------------------------------------------------------------------------------------------
+constexpr int BN_NARROW_MAXC = 16;
+
+template <typename AT>
+__global__ __launch_bounds__(256) void scale_shift_act_narrow_kernel(const AT* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, const AT* __restrict__ res, int ldr,
+                                                                     AT* __restrict__ y, int ldy, long long M, int C, int act, float slope) {
+  const int g = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  if (4 * g >= C) return;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int c = 4 * g + j; sc[j] = c < C ? scale[c] : 0.f; sh[j] = c < C ? shift[c] : 0.f; }
+  for (long long r = (long long)blockIdx.x * 64 + rl; r < M; r += (long long)gridDim.x * 64) {
+    const float4 xv = ld4f(x + (size_t)r * ldx + 4 * g);
+    float o[4] = {xv.x, xv.y, xv.z, xv.w};
+    float rr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (res) { const float4 rv = ld4f(res + (size_t)r * ldr + 4 * g); rr[0] = rv.x; rr[1] = rv.y; rr[2] = rv.z; rr[3] = rv.w; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (4 * g + j < C) ? apply_act(o[j] * sc[j] + sh[j] + rr[j], act, slope) : 0.f;
+    st4f(y + (size_t)r * ldy + 4 * g, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
+// pass 1: per-thread fp32 partials over <= rows_per_thread rows, workgroup fold in double, one atomic per channel per workgroup
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_narrow_kernel(const AT* __restrict__ dz, int lddz, const AT* __restrict__ z, int ldz,
+                                                                   const AT* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, long long M, int C, int act, float slope,
+                                                                   double* __restrict__ sums, int rows_per_thread) {
+  __shared__ double red[64][9];     // [row lane][4 x s1, 4 x s2] (+1 pad) per group, folded group by group
+  const int g = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, mu[4], rs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int c = 4 * g + j; mu[j] = c < C ? mean[c] : 0.f; rs[j] = c < C ? rstd[c] : 0.f; }
+  const float neg = act == SV_ACT_LRELU ? slope : 0.f;
+  if (4 * g < C) {
+    const long long r0 = (long long)blockIdx.x * 64 * rows_per_thread + rl;
+    for (int k = 0; k < rows_per_thread; ++k) {
+      const long long r = r0 + (long long)k * 64;
+      if (r >= M) break;
+      const float4 dv = ld4f(dz + (size_t)r * lddz + 4 * g), xv = ld4f(x + (size_t)r * ldx + 4 * g);
+      float d[4] = {dv.x, dv.y, dv.z, dv.w};
+      const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+      if (act != SV_ACT_NONE) {
+        const float4 zv = ld4f(z + (size_t)r * ldz + 4 * g);
+        const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] *= zz[j] > 0.f ? 1.f : neg;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] += d[j]; s2[j] += d[j] * (xx[j] - mu[j]) * rs[j]; }
+    }
+  }
+  for (int gg = 0; gg < 4; ++gg) {           // fold the 64 row lanes of one channel group at a time
+    __syncthreads();
+    if (g == gg) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { red[rl][j] = (double)s1[j]; red[rl][4 + j] = (double)s2[j]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      const int c = 4 * gg + (threadIdx.x & 3);
+      if (c < C) {
+        double a = 0.0;
+        for (int l = 0; l < 64; ++l) a += red[l][threadIdx.x];
+        atomicAdd(sums + (size_t)(blockIdx.x % BN_BWD_SLOTS) * 2 * C + (threadIdx.x >> 2) * C + c, a);
+      }
+    }
+  }
+}
+
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_narrow_kernel(const AT* __restrict__ dz, int lddz, const AT* __restrict__ z, int ldz,
+                                                                  const AT* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const double* __restrict__ sums, long long M, int C, int act, float slope,
+                                                                  int training, AT* __restrict__ dx, int lddx, AT* __restrict__ dres, int lddres) {
+  sums += (size_t)BN_BWD_SLOTS * 2 * C;     // the folded image
+  const int g = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  if (4 * g >= C) return;
+  // dx = k1*d - k2 - k3*x with per-channel constants (double: the mean-removal terms must cancel to rounding)
+  double k1[4], k2[4], k3[4];
+  const double invM = 1.0 / (double)M;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = 4 * g + j;
+    if (c < C) {
+      const double gm = gamma[c], rs = rstd[c], mu = mean[c];
+      k1[j] = gm * rs;
+      if (training) { const double a = sums[c] * invM, b = sums[C + c] * invM; k3[j] = gm * rs * b * rs; k2[j] = gm * rs * a - k3[j] * mu; }
+      else { k2[j] = 0.0; k3[j] = 0.0; }
+    } else { k1[j] = k2[j] = k3[j] = 0.0; }
+  }
+  const float neg = act == SV_ACT_LRELU ? slope : 0.f;
+  for (long long r = (long long)blockIdx.x * 64 + rl; r < M; r += (long long)gridDim.x * 64) {
+    const float4 dv = ld4f(dz + (size_t)r * lddz + 4 * g), xv = ld4f(x + (size_t)r * ldx + 4 * g);
+    float d[4] = {dv.x, dv.y, dv.z, dv.w};
+    const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (act != SV_ACT_NONE) {
+      const float4 zv = ld4f(z + (size_t)r * ldz + 4 * g);
+      const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] *= zz[j] > 0.f ? 1.f : neg;
+    }
+    if (dres) st4f(dres + (size_t)r * lddres + 4 * g, make_float4(d[0], d[1], d[2], d[3]));
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (float)(k1[j] * (double)d[j] - k2[j] - k3[j] * (double)xx[j]);
+    st4f(dx + (size_t)r * lddx + 4 * g, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
 // vector variant of pass 1 (C and the row strides multiples of 4): a thread owns 4 adjacent channels of a strided row
 // subset; G = min(C/4, 64) column groups x 256/G row lanes per workgroup, row lanes folded through LDS
 template <typename AT>
@@ -761,7 +878,13 @@ extern "C" int sv_scale_shift_act(const void* x, int ldx, const float* scale, co
   hipStream_t s = (hipStream_t)stream;
   const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (!residual || ldr % 4 == 0) && aligned4(act_dtype, x, y, residual) &&
                    (((uintptr_t)scale | (uintptr_t)shift) & 15) == 0;
-  if (vec) {
+  const bool narrow = !vec && C <= BN_NARROW_MAXC && (ldx % 4 == 0) && (ldy % 4 == 0) && ldx >= ((C + 3) & ~3) && ldy >= ((C + 3) & ~3) &&
+                      (!residual || (ldr % 4 == 0 && ldr >= ((C + 3) & ~3))) && aligned4(act_dtype, x, y, residual);
+  if (narrow) {
+    long long blocks = (M + 63) / 64; if (blocks > 8192) blocks = 8192;
+    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(scale_shift_act_narrow_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const AT*>(x), ldx, scale, shift,
+                                                  static_cast<const AT*>(residual), ldr, static_cast<AT*>(y), ldy, M, C, act, slope););
+  } else if (vec) {
     long long blocks = (M * (C / 4) + 255) / 256; if (blocks > 8192) blocks = 8192;
     SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(scale_shift_act_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const AT*>(x), ldx, scale, shift,
                                                   static_cast<const AT*>(residual), ldr, static_cast<AT*>(y), ldy, M, C, act, slope););
@@ -788,7 +911,19 @@ extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const
   SV_DISPATCH_ACT(act_dtype,
     const AT* dz_ = static_cast<const AT*>(dz); const AT* z_ = static_cast<const AT*>(z); const AT* x_ = static_cast<const AT*>(x);
     AT* dx_ = static_cast<AT*>(dx); AT* dres_ = static_cast<AT*>(dres);
-    if (vec) {
+    const int c4 = (C + 3) & ~3;
+    const bool narrow = !vec && C <= BN_NARROW_MAXC && (lddz % 4 == 0) && (ldx % 4 == 0) && (lddx % 4 == 0) && lddz >= c4 && ldx >= c4 && lddx >= c4 &&
+                        (!z || (ldz % 4 == 0 && ldz >= c4)) && (!dres || (lddres % 4 == 0 && lddres >= c4)) && aligned4(act_dtype, dz, z, x, dx, dres);
+    if (narrow) {
+      const int rpt = 16;
+      const long long nb = (M + 64LL * rpt - 1) / (64LL * rpt);
+      hipLaunchKernelGGL(bn_bwd_reduce_narrow_kernel<AT>, dim3((unsigned)nb), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope,
+                         sums_ws, rpt);
+      hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);
+      long long blocks = (M + 63) / 64; if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL(bn_bwd_apply_narrow_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
+                         act, slope, training, dx_, lddx, dres_, lddres);
+    } else if (vec) {
       const int G = C / 4 < 64 ? C / 4 : 64, RL = 256 / G;
       const int cg = cdiv(C / 4, G);
       long long splits = 2048 / cg; if (splits < 1) splits = 1;
