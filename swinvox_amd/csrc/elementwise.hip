@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dx_kernel(const AT* __restrict
     stf(dx + i, v);
   }
 }
-// dw[c][k], db[c]: one thread per (c,k) walks all images/positions (tiny tensors)
+// dw[c][k], db[c]: one thread per (c,k) walks a slice of the images (grid.y slices, one atomic per slice)
 template <typename AT>
 __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const AT* __restrict__ dy, const AT* __restrict__ x, float* __restrict__ dw,
                                                            float* __restrict__ db, int I, int C) {
@@ -293,15 +293,17 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const AT* __restrict_
   if (i >= C * 4) return;
   const int c = i >> 2, k = i & 3;
   float s = 0.f, sb = 0.f;
-  for (int n = 0; n < I; ++n)
+  const int per = (I + gridDim.y - 1) / gridDim.y;
+  const int n0 = blockIdx.y * per, n1 = n0 + per < I ? n0 + per : I;
+  for (int n = n0; n < n1; ++n)
     for (int o = 0; o < 9; ++o) {
       const int oy = o / 3, ox = o % 3;
       const float g = ldf(dy + ((size_t)n * 9 + o) * C + c);
       s += g * ldf(x + (((size_t)n * 7 + oy * 2 + (k >> 1)) * 7 + ox * 2 + (k & 1)) * C + c);
       sb += g;
     }
-  dw[i] += s;
-  if (k == 0 && db) db[c] += sb;
+  atomicAdd(dw + i, s);
+  if (k == 0 && db) atomicAdd(db + c, sb);
 }
 // bilinear 3->7 (align_corners=False) + residual: y = up(small) + x.  Separable taps per output index:
 // src = (dst+0.5)*3/7-0.5 clamped at 0 -> i0 = floor, frac; taps {1,0,0},{6/7,1/7,0},{3/7,4/7,0},{0,1,0},{0,4/7,3/7},{0,1/7,6/7},{0,0,1}
@@ -603,7 +605,7 @@ extern "C" int sv_dwconv2x2_bwd(const void* dy, const void* x, const float* w, v
   SV_REQUIRE_ACT(act_dtype);
   SV_DISPATCH_ACT(act_dtype,
     hipLaunchKernelGGL(dwconv_bwd_dx_kernel<AT>, dim3(grid_for((long long)I * 49 * C)), dim3(256), 0, STREAM, CA(dy), w, MA(dx), I, C);
-    hipLaunchKernelGGL(dwconv_bwd_w_kernel<AT>, dim3(cdiv(C * 4, 256)), dim3(256), 0, STREAM, CA(dy), CA(x), dw, db, I, C););
+    hipLaunchKernelGGL(dwconv_bwd_w_kernel<AT>, dim3(cdiv(C * 4, 256), I < 32 ? I : 32), dim3(256), 0, STREAM, CA(dy), CA(x), dw, db, I, C););
   return check_launch("sv_dwconv2x2_bwd");
 }
 extern "C" int sv_upsample3to7_add_fwd(const void* small, const void* x, int ldx, void* y, int I, int C, int act_dtype, void* stream) {

@@ -408,12 +408,12 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
       if (vec_out) {   // Co % 4 == 0 => the whole float4 is in range
         if (e.act_grad_src) {
           const float4 a = ld4f(static_cast<const AT*>(e.act_grad_src) + o);
-          v[0] *= act_grad(a.x, e.act_grad_kind, e.slope); v[1] *= act_grad(a.y, e.act_grad_kind, e.slope);
-          v[2] *= act_grad(a.z, e.act_grad_kind, e.slope); v[3] *= act_grad(a.w, e.act_grad_kind, e.slope);
+          v[0] *= act_grad_t<BF16>(a.x, e.act_grad_kind, e.slope); v[1] *= act_grad_t<BF16>(a.y, e.act_grad_kind, e.slope);
+          v[2] *= act_grad_t<BF16>(a.z, e.act_grad_kind, e.slope); v[3] *= act_grad_t<BF16>(a.w, e.act_grad_kind, e.slope);
         }
         if (e.pre_act) st4f(static_cast<AT*>(e.pre_act) + o, make_float4(v[0], v[1], v[2], v[3]));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], e.act, e.slope);
+        for (int j = 0; j < 4; ++j) v[j] = apply_act_t<BF16>(v[j], e.act, e.slope);
         if (e.residual) {
           const float4 r = ld4f(static_cast<const AT*>(e.residual) + (size_t)pos * e.ldr + n0);
           v[0] = r.x + sc * v[0]; v[1] = r.y + sc * v[1]; v[2] = r.z + sc * v[2]; v[3] = r.w + sc * v[3];
@@ -426,9 +426,9 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
         for (int j = 0; j < 4; ++j) {
           if (n0 + j < g.Co) {
             float t = v[j];
-            if (e.act_grad_src) t *= act_grad(ldf(static_cast<const AT*>(e.act_grad_src) + o + j), e.act_grad_kind, e.slope);
+            if (e.act_grad_src) t *= act_grad_t<BF16>(ldf(static_cast<const AT*>(e.act_grad_src) + o + j), e.act_grad_kind, e.slope);
             if (e.pre_act) stf(static_cast<AT*>(e.pre_act) + o + j, t);
-            t = apply_act(t, e.act, e.slope);
+            t = apply_act_t<BF16>(t, e.act, e.slope);
             if (e.residual) t = ldf(static_cast<const AT*>(e.residual) + (size_t)pos * e.ldr + n0 + j) + sc * t;
             stf(Y + o + j, t);
             s1[j] += t; s2[j] += t * t;
@@ -927,6 +927,7 @@ extern "C" int sv_colsum(const void* x, int rows, int cols, int ld, float* out, 
   if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * cols, s);
   const int cg = cdiv(cols, 64);
   int splits = 2048 / cg; if (splits < 1) splits = 1;
+  if (splits > 128) splits = 128;            // every split ends in one atomic per column: keep the contention per address low
   const int maxs = cdiv(rows, 64); if (splits > maxs) splits = maxs;
   const long long rpb = (rows + splits - 1) / splits;
   SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(colsum_kernel<AT>, dim3(cg, cdiv(rows, rpb)), dim3(256), 0, s, static_cast<const AT*>(x),

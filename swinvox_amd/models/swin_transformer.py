@@ -296,5 +296,4 @@ def swin_backward(st: SwinTransformer, tape, dfeats, I, grads):
     demb = empty(M, Ce, like=dx)
     ops.layernorm_bwd(dx, emb, pe.norm.weight, pm, pr, demb, grads[pe.norm.weight], grads[pe.norm.bias], M, Ce)
     S = st.img_size
-    bb.embed_spec.wgrad(demb, img, I, (1, S, S), grads[pe.proj.weight])
-    ops.colsum(demb, M, Ce, Ce, grads[pe.proj.bias])
+    bb.embed_spec.wgrad(demb, img, I, (1, S, S), grads[pe.proj.weight], db=grads[pe.proj.bias])
