@@ -61,6 +61,7 @@ typedef Tile<4, 2, 2, 2> TileDefault;   // 128 x 64, 8 waves of 32x32 (few regis
 typedef Tile<2, 2, 4, 4> TileWide;      // 128 x 128, 4 waves (register-heavy: measured slower, kept for reference)
 typedef Tile<2, 4, 4, 2> TileBig;       // 128 x 128, 8 waves (512 threads): halves the A re-reads of TileDefault at equal registers
 typedef Tile<4, 1, 2, 1> TileNarrow;    // 128 x 16
+typedef Tile<4, 2, 2, 3> Tile96;        // 128 x 96, 8 waves: the Swin channel counts are multiples of 96 (no padded columns for 96 / 192 / 288)
 
 __device__ __forceinline__ void store4(float* dst, float4 v) { *reinterpret_cast<float4*>(dst) = v; }
 __device__ __forceinline__ void store4(__bf16* dst, float4 v) {
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
           Cs[((wm * MT + mt) * 16 + lg * 4 + j) * LDC + (wn * NT + nt) * 16 + lr] = acc[mt][nt][j];
   }
   __syncthreads();
-  constexpr int C4 = BN / 4, CRPP = NTHR / C4, CPASS = BM / CRPP;
+  constexpr int C4 = BN / 4, CRPP = NTHR / C4, CPASS = (BM + CRPP - 1) / CRPP;   // 96-wide tile: 21 rows per pass, 8 idle threads
   const int c4 = tid % C4, cr = tid / C4;
   const int n0 = col0 + c4 * 4;
   const bool vec_out = ((e.ldc | e.col_off | g.Co) & 3) == 0 && (!e.residual || (e.ldr & 3) == 0);
@@ -388,12 +389,12 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
     for (int j = 0; j < 4; ++j) if (n0 + j < g.Co) bias4[j] = e.bias[n0 + j];
   }
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (n0 < g.Co) {
+  if (n0 < g.Co && cr < CRPP) {
 #pragma unroll 2
     for (int ps_ = 0; ps_ < CPASS; ++ps_) {
       const int row = cr + CRPP * ps_;
       const int m = row0 + row;
-      if (m >= Mrows) break;
+      if (row >= BM || m >= Mrows) break;
       int pos = m;
       if constexpr (TCONV) {
         int n_, d_, h_, w_;
@@ -756,9 +757,23 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, in
     else if (v8) hipLaunchKernelGGL((igemm_kernel<true, TCONV, TL, __bf16, __bf16, 8>), grid, dim3(TL::NTHR), 0, s, a);            \
     else hipLaunchKernelGGL((igemm_kernel<true, TCONV, TL, __bf16, __bf16, 4>), grid, dim3(TL::NTHR), 0, s, a);                    \
   } while (0)
+  // 96-wide tile for Co = 96 k when it wins the estimate  ceil(tiles / 256 CUs) x tile area x (1 + 2 % per extra pass over A)
+  // (the per-channel statistics epilogue needs a power-of-two column-group count, so BatchNorm producers never take it)
+  bool use96 = false;
+  if (Co % 96 == 0 && !a.e.stats) {
+    auto est = [&](int bm, int bn) {
+      const long long tn = cdiv(Co, bn), tiles = (long long)cdiv(M, bm) * tn * ncls;
+      return (double)((tiles + 255) / 256) * bm * bn * (1.0 + 0.02 * (tn - 1));
+    };
+    const double e96 = est(128, 96), e64 = est(128, 64), e128 = Co > 64 ? est(128, 128) : 1e300;
+    use96 = e96 <= e64 && e96 <= e128;
+  }
   if (Co <= 16) {
     dim3 grid(cdiv(M, TileNarrow::BM) * cdiv(Co, TileNarrow::BN), ncls);
     SV_LAUNCH_IG(TileNarrow);
+  } else if (use96) {
+    dim3 grid(cdiv(M, Tile96::BM) * cdiv(Co, Tile96::BN), ncls);
+    SV_LAUNCH_IG(Tile96);
   } else if (Co > 64 && (long long)cdiv(M, 128) * cdiv(Co, 128) * ncls >= 384) {   // 8-wave 128x128: one pass over A per 128 output columns
     dim3 grid(cdiv(M, TileBig::BM) * cdiv(Co, TileBig::BN), ncls);
     SV_LAUNCH_IG(TileBig);
