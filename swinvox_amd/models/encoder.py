@@ -53,13 +53,9 @@ class Bottleneck(nn.Module):
         didt = empty(dout.shape[0], Co, like=dout)
         db = self._c3.backward(c3, dout, Co, grads, dres=didt, lddres=Co)
         da = self._c2.backward(c2, db, self.conv2.out_channels, grads)
-        dx = self._c1.backward(c1, da, self.conv1.out_channels, grads)
-        if cd is not None:
-            dx2 = self._cd.backward(cd, didt, Co, grads)
-            call("sv_axpby", ptr(dx), ptr(dx2), ptr(dx), 1.0, 1.0, dx.numel())
-        else:
-            call("sv_axpby", ptr(dx), ptr(didt), ptr(dx), 1.0, 1.0, dx.numel())
-        return dx
+        # the skip-path gradient joins in the epilogue of conv1's data-gradient (no separate add pass)
+        skip = self._cd.backward(cd, didt, Co, grads) if cd is not None else didt
+        return self._c1.backward(c1, da, self.conv1.out_channels, grads, dx_epi=dict(residual=skip, ldr=self.conv1.in_channels))
 
 
 def _res_layer(inplanes, planes, blocks, stride):
