@@ -163,6 +163,8 @@ size_t sv_bn_bwd_workspace_doubles(int C);   /* size of sums_ws below */
 int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const void* x, int ldx, const float* gamma,
               const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
               void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws /* sv_bn_bwd_workspace_doubles(C) doubles, ZERO on entry */,
+              const float* fwd_scale, const float* fwd_shift /* optional: with z == NULL the activation mask is recomputed as
+              x*fwd_scale + fwd_shift > 0 (valid when the forward added no residual) - saves one tensor read per pass */,
               int act_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

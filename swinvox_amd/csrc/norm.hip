@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const AT* __restri
     const long long r = i / cv; const int c = (int)(i - r * cv) * 4;
     const float4 xv = ld4f(x + (size_t)r * ldx + c);
     const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
-    float o[4] = {xv.x * sc.x + sh.x, xv.y * sc.y + sh.y, xv.z * sc.z + sh.z, xv.w * sc.w + sh.w};
+    float o[4] = {__fmaf_rn(xv.x, sc.x, sh.x), __fmaf_rn(xv.y, sc.y, sh.y), __fmaf_rn(xv.z, sc.z, sh.z), __fmaf_rn(xv.w, sc.w, sh.w)};
     if (res) {
       const float4 rv = ld4f(res + (size_t)r * ldr + c);
       o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_scalar_kernel(const AT* _
   const long long total = M * C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / C; const int c = (int)(i - r * C);
-    float o = ldf(x + (size_t)r * ldx + c) * scale[c] + shift[c];
+    float o = __fmaf_rn(ldf(x + (size_t)r * ldx + c), scale[c], shift[c]);
     if (res) o += ldf(res + (size_t)r * ldr + c);
     stf(y + (size_t)r * ldy + c, apply_act(o, act, slope));
   }
@@ -443,7 +443,8 @@ template <typename AT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const AT* __restrict__ dz, int lddz, const AT* __restrict__ z, int ldz,
                                                             const AT* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, long long M, int C, int act, float slope,
-                                                            double* __restrict__ sums, long long rows_per_block) {
+                                                            double* __restrict__ sums, long long rows_per_block,
+                                                            const float* __restrict__ fsc, const float* __restrict__ fsh) {
   __shared__ double r1[4][64], r2[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const long long r0 = (long long)blockIdx.y * rows_per_block;
@@ -451,6 +452,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const AT* __restrict
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     const float mu = mean[c], rs = rstd[c];
+    const float msc = z ? 0.f : fsc[c], msh = z ? 0.f : fsh[c];     // no saved output: the mask is recomputed from x
     long long r = r0 + rl;
     for (; r + 12 < r1e; r += 16) {   // 4 rows in flight per thread (independent loads), then the serial tail
       float d[4], xv[4], zv[4];
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const AT* __restrict
       for (int u = 0; u < 4; ++u) {
         d[u] = ldf(dz + (size_t)(r + 4 * u) * lddz + c);
         xv[u] = ldf(x + (size_t)(r + 4 * u) * ldx + c);
-        zv[u] = act != SV_ACT_NONE ? ldf(z + (size_t)(r + 4 * u) * ldz + c) : 1.f;
+        zv[u] = act != SV_ACT_NONE ? (z ? ldf(z + (size_t)(r + 4 * u) * ldz + c) : __fmaf_rn(xv[u], msc, msh)) : 1.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -468,8 +470,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const AT* __restrict
     }
     for (; r < r1e; r += 4) {
       float d = ldf(dz + (size_t)r * lddz + c);
-      if (act != SV_ACT_NONE) d *= (ldf(z + (size_t)r * ldz + c) > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
-      s1 += (double)d; s2 += (double)(d * (ldf(x + (size_t)r * ldx + c) - mu) * rs);
+      const float xq = ldf(x + (size_t)r * ldx + c);
+      if (act != SV_ACT_NONE) d *= ((z ? ldf(z + (size_t)r * ldz + c) : __fmaf_rn(xq, msc, msh)) > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
+      s1 += (double)d; s2 += (double)(d * (xq - mu) * rs);
     }
   }
   r1[rl][threadIdx.x & 63] = s1; r2[rl][threadIdx.x & 63] = s2;
@@ -489,21 +492,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const AT* __restrict_
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const double* __restrict__ sums, long long M, int C, int act, float slope,
                                                            int training, AT* __restrict__ dx, int lddx, AT* __restrict__ dres,
-                                                           int lddres, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           int lddres, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           const float* __restrict__ fsc, const float* __restrict__ fsh) {
   const long long total = M * C;
   const double invM = 1.0 / (double)M;
   sums += (size_t)BN_BWD_SLOTS * 2 * C;     // the folded image written by the reduce pass
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long r = i / C; const int c = (int)(i - r * C);
     float d = ldf(dz + (size_t)r * lddz + c);
-    if (act != SV_ACT_NONE) d *= (ldf(z + (size_t)r * ldz + c) > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
+    const float xq = ldf(x + (size_t)r * ldx + c);
+    if (act != SV_ACT_NONE) d *= ((z ? ldf(z + (size_t)r * ldz + c) : __fmaf_rn(xq, fsc[c], fsh[c])) > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
     if (dres) stf(dres + (size_t)r * lddres + c, d);
     const float rs = rstd[c];
     float o;
     if (training) {
       // double arithmetic for the mean-subtraction terms: sum_r dx must vanish to rounding, otherwise the residual is
       // amplified by every later reduction over positions (torch's CPU kernel evaluates this expression in double too)
-      const double xh = ((double)ldf(x + (size_t)r * ldx + c) - (double)mean[c]) * (double)rs;
+      const double xh = ((double)xq - (double)mean[c]) * (double)rs;
       o = (float)((double)gamma[c] * (double)rs * ((double)d - sums[c] * invM - xh * (sums[C + c] * invM)));
     } else {
       o = d * gamma[c] * rs;
@@ -519,7 +524,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const AT* __restr
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const double* __restrict__ sums, long long M, int C, int act, float slope,
                                                                int training, AT* __restrict__ dx, int lddx, AT* __restrict__ dres,
-                                                               int lddres, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                               int lddres, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               const float* __restrict__ fsc, const float* __restrict__ fsh) {
   const int cv = C >> 2;
   const long long total = M * cv;
   const double invM = 1.0 / (double)M;
@@ -528,17 +534,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const AT* __restr
     const long long r = i / cv; const int c = (int)(i - r * cv) * 4;
     const float4 dv = ld4f(dz + (size_t)r * lddz + c);
     float d[4] = {dv.x, dv.y, dv.z, dv.w};
+    const float4 xv = ld4f(x + (size_t)r * ldx + c);
+    const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
     if (act != SV_ACT_NONE) {
-      const float4 zv = ld4f(z + (size_t)r * ldz + c);
-      const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+      float zz[4];
+      if (z) { const float4 zv = ld4f(z + (size_t)r * ldz + c); zz[0] = zv.x; zz[1] = zv.y; zz[2] = zv.z; zz[3] = zv.w; }
+      else {   // no saved output: recompute the pre-activation exactly as the forward did
+        const float4 sc = *reinterpret_cast<const float4*>(fsc + c), sh = *reinterpret_cast<const float4*>(fsh + c);
+        zz[0] = __fmaf_rn(xx[0], sc.x, sh.x); zz[1] = __fmaf_rn(xx[1], sc.y, sh.y); zz[2] = __fmaf_rn(xx[2], sc.z, sh.z); zz[3] = __fmaf_rn(xx[3], sc.w, sh.w);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) d[j] *= (zz[j] > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
     }
     if (dres) st4f(dres + (size_t)r * lddres + c, make_float4(d[0], d[1], d[2], d[3]));
     float o[4];
     if (training) {
-      const float4 xv = ld4f(x + (size_t)r * ldx + c);
-      const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const double rs = (double)rstd[c + j];
@@ -576,7 +586,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_narrow_kernel(const AT* _
     float rr[4] = {0.f, 0.f, 0.f, 0.f};
     if (res) { const float4 rv = ld4f(res + (size_t)r * ldr + 4 * g); rr[0] = rv.x; rr[1] = rv.y; rr[2] = rv.z; rr[3] = rv.w; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (4 * g + j < C) ? apply_act(o[j] * sc[j] + sh[j] + rr[j], act, slope) : 0.f;
+    for (int j = 0; j < 4; ++j) o[j] = (4 * g + j < C) ? apply_act(__fmaf_rn(o[j], sc[j], sh[j]) + rr[j], act, slope) : 0.f;
     st4f(y + (size_t)r * ldy + 4 * g, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
@@ -586,12 +596,17 @@ template <typename AT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_narrow_kernel(const AT* __restrict__ dz, int lddz, const AT* __restrict__ z, int ldz,
                                                                    const AT* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                                    const float* __restrict__ rstd, long long M, int C, int act, float slope,
-                                                                   double* __restrict__ sums, int rows_per_thread) {
+                                                                   double* __restrict__ sums, int rows_per_thread,
+                                                                   const float* __restrict__ fsc, const float* __restrict__ fsh) {
   __shared__ double red[64][9];     // [row lane][4 x s1, 4 x s2] (+1 pad) per group, folded group by group
   const int g = threadIdx.x & 3, rl = threadIdx.x >> 2;
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, mu[4], rs[4];
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, mu[4], rs[4], msc[4], msh[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { const int c = 4 * g + j; mu[j] = c < C ? mean[c] : 0.f; rs[j] = c < C ? rstd[c] : 0.f; }
+  for (int j = 0; j < 4; ++j) {
+    const int c = 4 * g + j;
+    mu[j] = c < C ? mean[c] : 0.f; rs[j] = c < C ? rstd[c] : 0.f;
+    msc[j] = (!z && fsc && c < C) ? fsc[c] : 0.f; msh[j] = (!z && fsh && c < C) ? fsh[c] : 0.f;
+  }
   const float neg = act == SV_ACT_LRELU ? slope : 0.f;
   if (4 * g < C) {
     const long long r0 = (long long)blockIdx.x * 64 * rows_per_thread + rl;
@@ -602,8 +617,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_narrow_kernel(const AT* __r
       float d[4] = {dv.x, dv.y, dv.z, dv.w};
       const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
       if (act != SV_ACT_NONE) {
-        const float4 zv = ld4f(z + (size_t)r * ldz + 4 * g);
-        const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+        float zz[4];
+        if (z) { const float4 zv = ld4f(z + (size_t)r * ldz + 4 * g); zz[0] = zv.x; zz[1] = zv.y; zz[2] = zv.z; zz[3] = zv.w; }
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) zz[j] = __fmaf_rn(xx[j], msc[j], msh[j]);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] *= zz[j] > 0.f ? 1.f : neg;
       }
@@ -634,10 +653,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_narrow_kernel(const AT* __re
                                                                   const AT* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                   const double* __restrict__ sums, long long M, int C, int act, float slope,
-                                                                  int training, AT* __restrict__ dx, int lddx, AT* __restrict__ dres, int lddres) {
+                                                                  int training, AT* __restrict__ dx, int lddx, AT* __restrict__ dres, int lddres,
+                                                                  const float* __restrict__ fsc, const float* __restrict__ fsh) {
   sums += (size_t)BN_BWD_SLOTS * 2 * C;     // the folded image
   const int g = threadIdx.x & 3, rl = threadIdx.x >> 2;
   if (4 * g >= C) return;
+  float msc[4], msh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int c = 4 * g + j; msc[j] = (!z && fsc && c < C) ? fsc[c] : 0.f; msh[j] = (!z && fsh && c < C) ? fsh[c] : 0.f; }
   // dx = k1*d - k2 - k3*x with per-channel constants (double: the mean-removal terms must cancel to rounding)
   double k1[4], k2[4], k3[4];
   const double invM = 1.0 / (double)M;
@@ -657,8 +680,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_narrow_kernel(const AT* __re
     float d[4] = {dv.x, dv.y, dv.z, dv.w};
     const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
     if (act != SV_ACT_NONE) {
-      const float4 zv = ld4f(z + (size_t)r * ldz + 4 * g);
-      const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+      float zz[4];
+      if (z) { const float4 zv = ld4f(z + (size_t)r * ldz + 4 * g); zz[0] = zv.x; zz[1] = zv.y; zz[2] = zv.z; zz[3] = zv.w; }
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zz[j] = __fmaf_rn(xx[j], msc[j], msh[j]);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) d[j] *= zz[j] > 0.f ? 1.f : neg;
     }
@@ -676,7 +703,8 @@ template <typename AT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __restrict__ dz, int lddz, const AT* __restrict__ z, int ldz,
                                                                 const AT* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, long long M, int C, int act, float slope,
-                                                                double* __restrict__ sums, long long rows_per_block, int G) {
+                                                                double* __restrict__ sums, long long rows_per_block, int G,
+                                                                const float* __restrict__ fsc, const float* __restrict__ fsh) {
   __shared__ double red[256][9];   // [thread][8 partials] (+1 pad)
   const int gq = threadIdx.x % G, rl = threadIdx.x / G, RL = 256 / G;
   const int c = (blockIdx.x * G + gq) * 4;
@@ -685,6 +713,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __rest
   double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
   if (c < C && rl < RL) {
     const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+    float4 msc = make_float4(0.f, 0.f, 0.f, 0.f), msh = msc;          // no saved output: the mask is recomputed from x
+    if (!z && act != SV_ACT_NONE) { msc = *reinterpret_cast<const float4*>(fsc + c); msh = *reinterpret_cast<const float4*>(fsh + c); }
     const float neg = act == SV_ACT_LRELU ? slope : 0.f;
     long long r = r0 + rl;
     for (; r + RL < r1e; r += 2 * RL) {   // two rows in flight
@@ -692,7 +722,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __rest
       const float4 x0 = ld4f(x + (size_t)r * ldx + c), x1 = ld4f(x + (size_t)(r + RL) * ldx + c);
       float a0[4] = {d0.x, d0.y, d0.z, d0.w}, a1[4] = {d1.x, d1.y, d1.z, d1.w};
       if (act != SV_ACT_NONE) {
-        const float4 z0 = ld4f(z + (size_t)r * ldz + c), z1 = ld4f(z + (size_t)(r + RL) * ldz + c);
+        float4 z0, z1;
+        if (z) { z0 = ld4f(z + (size_t)r * ldz + c); z1 = ld4f(z + (size_t)(r + RL) * ldz + c); }
+        else {
+          z0 = make_float4(__fmaf_rn(x0.x, msc.x, msh.x), __fmaf_rn(x0.y, msc.y, msh.y), __fmaf_rn(x0.z, msc.z, msh.z), __fmaf_rn(x0.w, msc.w, msh.w));
+          z1 = make_float4(__fmaf_rn(x1.x, msc.x, msh.x), __fmaf_rn(x1.y, msc.y, msh.y), __fmaf_rn(x1.z, msc.z, msh.z), __fmaf_rn(x1.w, msc.w, msh.w));
+        }
         const float q0[4] = {z0.x, z0.y, z0.z, z0.w}, q1[4] = {z1.x, z1.y, z1.z, z1.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a0[j] *= q0[j] > 0.f ? 1.f : neg; a1[j] *= q1[j] > 0.f ? 1.f : neg; }
@@ -709,7 +744,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __rest
       const float4 d0 = ld4f(dz + (size_t)r * lddz + c), x0 = ld4f(x + (size_t)r * ldx + c);
       float a0[4] = {d0.x, d0.y, d0.z, d0.w};
       if (act != SV_ACT_NONE) {
-        const float4 z0 = ld4f(z + (size_t)r * ldz + c);
+        const float4 z0 = z ? ld4f(z + (size_t)r * ldz + c)
+                            : make_float4(__fmaf_rn(x0.x, msc.x, msh.x), __fmaf_rn(x0.y, msc.y, msh.y), __fmaf_rn(x0.z, msc.z, msh.z), __fmaf_rn(x0.w, msc.w, msh.w));
         const float q0[4] = {z0.x, z0.y, z0.z, z0.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) a0[j] *= q0[j] > 0.f ? 1.f : neg;
@@ -900,10 +936,11 @@ extern "C" size_t sv_bn_bwd_workspace_doubles(int C) { return (size_t)(BN_BWD_SL
 
 extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const void* x, int ldx, const float* gamma,
                          const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
-                         void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws, int act_dtype,
-                         void* stream) {
+                         void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws,
+                         const float* fwd_scale, const float* fwd_shift, int act_dtype, void* stream) {
   SV_REQUIRE(dz && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && sums_ws && M > 0 && C > 0, "bn_bwd: null/empty argument");
-  SV_REQUIRE(act == SV_ACT_NONE || z, "bn_bwd: the activation mask needs the forward output z");
+  SV_REQUIRE(act == SV_ACT_NONE || z || (fwd_scale && fwd_shift), "bn_bwd: the activation mask needs the forward output z or the forward scale/shift");
+  const float* fsc = fwd_scale; const float* fsh = fwd_shift;
   SV_REQUIRE_ACT(act_dtype);
   hipStream_t s = (hipStream_t)stream;   // sums_ws: sv_bn_bwd_workspace_doubles(C) doubles, ZERO on entry (e.g. a slice of one pre-zeroed arena)
   const bool vec = (C % 4 == 0) && (lddz % 4 == 0) && (ldx % 4 == 0) && (lddx % 4 == 0) && (!z || ldz % 4 == 0) && (!dres || lddres % 4 == 0) &&
@@ -918,11 +955,11 @@ extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const
       const int rpt = 16;
       const long long nb = (M + 64LL * rpt - 1) / (64LL * rpt);
       hipLaunchKernelGGL(bn_bwd_reduce_narrow_kernel<AT>, dim3((unsigned)nb), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope,
-                         sums_ws, rpt);
+                         sums_ws, rpt, fsc, fsh);
       hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);
       long long blocks = (M + 63) / 64; if (blocks > 8192) blocks = 8192;
       hipLaunchKernelGGL(bn_bwd_apply_narrow_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
-                         act, slope, training, dx_, lddx, dres_, lddres);
+                         act, slope, training, dx_, lddx, dres_, lddres, fsc, fsh);
     } else if (vec) {
       const int G = C / 4 < 64 ? C / 4 : 64, RL = 256 / G;
       const int cg = cdiv(C / 4, G);
@@ -930,21 +967,21 @@ extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const
       const long long maxs = (M + 2 * RL - 1) / (2 * RL); if (splits > maxs) splits = maxs;
       const long long rpb = (M + splits - 1) / splits;
       hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope,
-                         sums_ws, rpb, G);
+                         sums_ws, rpb, G, fsc, fsh);
       hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);
       long long blocks = (M * (C / 4) + 255) / 256; if (blocks > 8192) blocks = 8192;
       hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
-                         act, slope, training, dx_, lddx, dres_, lddres, dgamma, dbeta);
+                         act, slope, training, dx_, lddx, dres_, lddres, dgamma, dbeta, fsc, fsh);
     } else {
       const int cg = cdiv(C, 64);
       long long splits = 2048 / cg; if (splits < 1) splits = 1;
       const long long maxs = (M + 63) / 64; if (splits > maxs) splits = maxs;
       const long long rpb = (M + splits - 1) / splits;
-      hipLaunchKernelGGL(bn_bwd_reduce_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope, sums_ws, rpb);
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope, sums_ws, rpb, fsc, fsh);
       hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);
       long long blocks = (M * C + 255) / 256; if (blocks > 8192) blocks = 8192;
       hipLaunchKernelGGL(bn_bwd_apply_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
-                         act, slope, training, dx_, lddx, dres_, lddres, dgamma, dbeta);
+                         act, slope, training, dx_, lddx, dres_, lddres, dgamma, dbeta, fsc, fsh);
     });
   return check_launch("sv_bn_bwd");
 }

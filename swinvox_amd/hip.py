@@ -74,7 +74,7 @@ _PROTOS = {
     "sv_bn_stats": (_I, [_P, _L, _I, _I, _P]),
     "sv_bn_finalize": (_I, [_P, _L, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _I]),
     "sv_scale_shift_act": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _F]),
-    "sv_bn_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _L, _I, _I, _F, _I, _P, _I, _P, _I, _P, _P, _P]),
+    "sv_bn_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _L, _I, _I, _F, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P]),
     "sv_window_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "sv_window_attention_bwd_workspace_floats": (C.c_size_t, None, [_I]),
     "sv_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),

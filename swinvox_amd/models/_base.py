@@ -135,7 +135,8 @@ class ConvBnAct:
         if z is None:
             z, ldz = empty(M, sp.cout, like=x), sp.cout
         st.apply(y, sp.cout, z, ldz, self.act, self.slope, residual, ldr)
-        return z, og, (x, ldi, y, z, ldz, st, n, in_grid, M)
+        # without a residual the backward recomputes the activation mask from y (scale*y + shift > 0) and never reads z
+        return z, og, (x, ldi, y, z if residual is not None else None, ldz, st, n, in_grid, M)
 
     def backward(self, ctx, dz, lddz, grads, *, need_dx=True, dres=None, lddres=0, dx=None, lddx=None, dx_epi=None):
         x, ldi, y, z, ldz, st, n, in_grid, M = ctx

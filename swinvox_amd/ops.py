@@ -463,8 +463,10 @@ class BatchNormState:
 
     def backward(self, dz, lddz, z, ldz, x, ldx, dx, lddx, dgamma, dbeta, act=ACT_NONE, slope=0.0, dres=None, lddres=0):
         ws = zeros_f64((BN_BWD_SLOTS + 1) * 2 * self.C + 2, dz.device)     # sv_bn_bwd_workspace_doubles(C), zero on entry
+        # z = None: the forward added no residual, so the activation mask is recomputed from x (one tensor read less per pass)
         call("sv_bn_bwd", ptr(dz), lddz, ptr(z), ldz, ptr(x), ldx, ptr(self.bn.weight), ptr(self.mean), ptr(self.rstd), self.M, self.C,
-             act, slope, 1 if self.training else 0, ptr(dx), lddx, ptr(dres), lddres, ptr(dgamma), ptr(dbeta), ptr(ws))
+             act, slope, 1 if self.training else 0, ptr(dx), lddx, ptr(dres), lddres, ptr(dgamma), ptr(dbeta), ptr(ws),
+             ptr(self.scale), ptr(self.shift))
 
 
 def transpose(src, dst, batch, R, Cc, lds=None, ldd=None, sb=None, db=None):
