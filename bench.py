@@ -27,7 +27,7 @@ PEAK_HBM_GBS = 8000.0
 FWD_GFLOP_PER_VIEW = {1: 21.0, 8: 19.4, 24: 19.3}   # forward; fwd+bwd = 3x
 
 
-def cpu_baseline(views: int, threads: int, batch: int = 2, steps: int = 2):
+def cpu_baseline(views: int, threads: int, batch: int = 2, steps: int = 6):
     """The CPU oracle (our restatement of the reference path, pinned against it in the build container) timed on this
     host's cores on a bounded sample: one untimed warm-up + `steps` timed fwd+bwd steps of `batch` x `views` views, fp32
     (about 10 s of CPU work on 16 cores)."""
