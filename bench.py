@@ -62,7 +62,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="samples per GPU (x --views images); 8 = the reference's batch 64 over 8 GPUs")
+    ap.add_argument("--batch", type=int, default=32,
+                    help="samples per GPU (x --views images each); 32 = the reference's cfg.CONST.BATCH_SIZE (config.py:64)")
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--math", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--storage", default="bf16", choices=["bf16", "f32"], help="HBM element type of the activations inside the modules")
