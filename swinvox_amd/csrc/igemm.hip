@@ -181,6 +181,113 @@ __device__ __forceinline__ void decode_row(int m, int c0, int c1, int c2, int& n
 }
 
 // ------------------------------------------------------------------------------------------------
+// tile epilogue shared by the gather kernels: accumulators -> LDS tile -> cooperative, row-contiguous vector reads/writes with
+// the fused bias / activation(-gradient) / residual / pre-activation copy / per-channel statistics.  Every wave must have
+// finished reading the operand tiles (Cs aliases them) before the call.
+// ------------------------------------------------------------------------------------------------
+template <bool BF16, bool TCONV, typename TL, typename AT>
+__device__ __forceinline__ void tile_epilogue(const IGemmArgs& p, const ClassInfo& ci, int cnt0, int cnt1, int cnt2, float* Cs, float* red,
+                                              const f32x4 (&acc)[TL::MT][TL::NT], int row0, int col0, int Mrows) {
+  constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT, NTHR = TL::NTHR, NW = TL::NW, LDC = BN + 4;
+  const Geom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / TL::WN, wn = wave % TL::WN;
+  AT* __restrict__ Y = static_cast<AT*>(p.y);
+  const Epi& e = p.e;
+  {
+    const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          Cs[((wm * MT + mt) * 16 + lg * 4 + j) * LDC + (wn * NT + nt) * 16 + lr] = acc[mt][nt][j];
+  }
+  __syncthreads();
+  constexpr int C4 = BN / 4, CRPP = NTHR / C4, CPASS = (BM + CRPP - 1) / CRPP;   // 96-wide tile: 21 rows per pass, 8 idle threads
+  const int c4 = tid % C4, cr = tid / C4;
+  const int n0 = col0 + c4 * 4;
+  const bool vec_out = ((e.ldc | e.col_off | g.Co) & 3) == 0 && (!e.residual || (e.ldr & 3) == 0);
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (e.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (n0 + j < g.Co) bias4[j] = e.bias[n0 + j];
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n0 < g.Co && cr < CRPP) {
+#pragma unroll 2
+    for (int ps_ = 0; ps_ < CPASS; ++ps_) {
+      const int row = cr + CRPP * ps_;
+      const int m = row0 + row;
+      if (row >= BM || m >= Mrows) break;
+      int pos = m;
+      if constexpr (TCONV) {
+        int n_, d_, h_, w_;
+        decode_row(m, cnt0, cnt1, cnt2, n_, d_, h_, w_);
+        const int od = ci.o0[0] + g.sd * d_, oh = ci.o0[1] + g.sh * h_, ow = ci.o0[2] + g.sw * w_;
+        pos = ((n_ * g.Do + od) * g.Ho + oh) * g.Wo + ow;
+      }
+      const float4 c = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
+      float v[4] = {c.x + bias4[0], c.y + bias4[1], c.z + bias4[2], c.w + bias4[3]};
+      const size_t o = (size_t)pos * e.ldc + e.col_off + n0;
+      const float sc = (e.residual && e.row_scale) ? e.row_scale[pos / e.rows_per_scale] : 1.f;
+      if (vec_out) {   // Co % 4 == 0 => the whole float4 is in range
+        if (e.act_grad_src) {
+          const float4 a = ld4f(static_cast<const AT*>(e.act_grad_src) + o);
+          v[0] *= act_grad_t<BF16>(a.x, e.act_grad_kind, e.slope); v[1] *= act_grad_t<BF16>(a.y, e.act_grad_kind, e.slope);
+          v[2] *= act_grad_t<BF16>(a.z, e.act_grad_kind, e.slope); v[3] *= act_grad_t<BF16>(a.w, e.act_grad_kind, e.slope);
+        }
+        if (e.pre_act) st4f(static_cast<AT*>(e.pre_act) + o, make_float4(v[0], v[1], v[2], v[3]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = apply_act_t<BF16>(v[j], e.act, e.slope);
+        if (e.residual) {
+          const float4 r = ld4f(static_cast<const AT*>(e.residual) + (size_t)pos * e.ldr + n0);
+          v[0] = r.x + sc * v[0]; v[1] = r.y + sc * v[1]; v[2] = r.z + sc * v[2]; v[3] = r.w + sc * v[3];
+        }
+        st4f(Y + o, make_float4(v[0], v[1], v[2], v[3]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (n0 + j < g.Co) {
+            float t = v[j];
+            if (e.act_grad_src) t *= act_grad_t<BF16>(ldf(static_cast<const AT*>(e.act_grad_src) + o + j), e.act_grad_kind, e.slope);
+            if (e.pre_act) stf(static_cast<AT*>(e.pre_act) + o + j, t);
+            t = apply_act_t<BF16>(t, e.act, e.slope);
+            if (e.residual) t = ldf(static_cast<const AT*>(e.residual) + (size_t)pos * e.ldr + n0 + j) + sc * t;
+            stf(Y + o + j, t);
+            s1[j] += t; s2[j] += t * t;
+          }
+        }
+      }
+    }
+  }
+  if (e.stats) {  // per-channel sum / sumsq of what was stored: lanes sharing a column group, then the 4 waves, then ONE
+                  // double atomic per column per workgroup into one of SV_BN_SLOTS accumulator slots (spreads contention)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int o = C4; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+    if ((lane / C4) == 0 || C4 >= 64) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { red[(wave * BN + c4 * 4 + j) * 2] = s1[j]; red[(wave * BN + c4 * 4 + j) * 2 + 1] = s2[j]; }
+    }
+    __syncthreads();
+    if (tid < BN && col0 + tid < g.Co) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+      double* st = e.stats + (size_t)((row0 / BM) % SV_BN_SLOTS) * 2 * g.Co;
+      atomicAdd(st + col0 + tid, (double)a);
+      atomicAdd(st + g.Co + col0 + tid, (double)b);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------------
 // AT = activation storage type, WT = packed-weight type, VEC = elements per operand load (4, or 8 = 16 bytes of bf16)
@@ -366,98 +473,100 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
     }
   }
 
-  // ---- epilogue: accumulators -> LDS tile -> cooperative, row-contiguous (16-byte) reads/writes -----------------
-  const Epi& e = p.e;
-  {
-    const int lr = lane & 15, lg = lane >> 4;
+  tile_epilogue<BF16, TCONV, TL, AT>(p, ci, cnt0, cnt1, cnt2, Cs, red, acc, row0, col0, Mrows);
+}
+
+// ------------------------------------------------------------------------------------------------
+// persistent dense kernel (bf16 MFMA, bf16 storage): Linear layers and 1x1 / stride-1 convolutions, i.e. gathered row m
+// is the row m*ldi of x.  A tile with few K steps spends most of its ~10 us on everything around the MFMA loop
+// (workgroup start, first-slab latency, epilogue); here a workgroup walks tiles t = b, b + G, ... and issues the loads of
+// the NEXT tile's first operand slab before the epilogue of the current one, so that latency hides behind the epilogue
+// and the start-up cost is paid once.  Same tiles, loader mapping, LDS layout and epilogue as igemm_kernel.
+// ------------------------------------------------------------------------------------------------
+template <typename TL, typename AT, typename WT, int VEC>
+__global__ __launch_bounds__(TL::NTHR, TL::NTHR >= 512 ? 4 : 2) void gemm_dense_kernel(const IGemmArgs p, int ntiles) {
+  typedef __bf16 LT;
+  constexpr int BK = Cfg<true>::BK, LD = BK + Cfg<true>::PAD;
+  constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT;
+  constexpr int TPR = BK / VEC, NTHR = TL::NTHR, NW = TL::NW, RPP = NTHR / TPR;
+  constexpr int NA = BM / RPP, NB = (BN + RPP - 1) / RPP, LDC = BN + 4;
+  constexpr int STAGE = (BM + BN) * LD;
+  constexpr int AB_BYTES = 2 * STAGE * (int)sizeof(LT), C_BYTES = BM * LDC * 4;
+  __shared__ __attribute__((aligned(16))) char smem[AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES];
+  __shared__ float red[NW * BN * 2];
+  typedef typename VecN<AT, VEC>::type AV;
+  typedef typename VecN<WT, VEC>::type WV;
+  LT* As = reinterpret_cast<LT*>(smem);
+  LT* Bs = As + BM * LD;
+  float* Cs = reinterpret_cast<float*>(smem);
+  const AT* __restrict__ X = static_cast<const AT*>(p.x);
+  const WT* __restrict__ Wt = static_cast<const WT*>(p.w);
+  const Geom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / TL::WN, wn = wave % TL::WN;
+  const int Mrows = g.N * g.Do * g.Ho * g.Wo, K = g.Ci;
+  const int tiles_n = (g.Co + BN - 1) / BN, nk = (K + BK - 1) / BK;
+  const int kq = (tid % TPR) * VEC, rb = tid / TPR;
+  const ClassInfo ci{};
+
+  AV ra[NA];
+  WV rbv[NB];
+  auto load_slab = [&](int row0, int col0, int k0) {
+    const bool kok = k0 + kq < K;                       // K % VEC == 0: a chunk is whole or absent
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int m = row0 + rb + RPP * i;
+      ra[i] = (kok && m < Mrows) ? VecN<AT, VEC>::load(X + (size_t)m * g.ldi + k0 + kq) : VecN<AT, VEC>::zero();
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int nl = rb + RPP * i, n = col0 + nl;
+      rbv[i] = (kok && nl < BN && n < g.Co) ? VecN<WT, VEC>::load(Wt + (size_t)n * p.Ktot + k0 + kq) : VecN<WT, VEC>::zero();
+    }
+  };
+  auto store_slab = [&](int buf) {
+    LT* A_ = As + buf * STAGE;
+    LT* B_ = Bs + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) store4(A_ + (rb + RPP * i) * LD + kq, ra[i]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (rb + RPP * i < BN) store4(B_ + (rb + RPP * i) * LD + kq, rbv[i]);
+  };
+  // tile of this workgroup in window `it` (windows of gridDim.x consecutive tiles, XCD-aware order inside a window)
+  auto tile_of = [&](int it, int& row0, int& col0) {
+    const int w0 = it * (int)gridDim.x;
+    int left = ntiles - w0; if (left > (int)gridDim.x) left = (int)gridDim.x;
+    if (left <= 0 || (int)blockIdx.x >= left) return false;
+    const int tlin = w0 + xcd_remap(blockIdx.x, left);
+    row0 = (tlin / tiles_n) * BM; col0 = (tlin % tiles_n) * BN;
+    return true;
+  };
+
+  int row0, col0, it = 0;
+  bool have = tile_of(0, row0, col0);
+  if (have) load_slab(row0, col0, 0);
+  while (have) {
+    store_slab(0);
+    __syncthreads();
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          Cs[((wm * MT + mt) * 16 + lg * 4 + j) * LDC + (wn * NT + nt) * 16 + lr] = acc[mt][nt][j];
-  }
-  __syncthreads();
-  constexpr int C4 = BN / 4, CRPP = NTHR / C4, CPASS = (BM + CRPP - 1) / CRPP;   // 96-wide tile: 21 rows per pass, 8 idle threads
-  const int c4 = tid % C4, cr = tid / C4;
-  const int n0 = col0 + c4 * 4;
-  const bool vec_out = ((e.ldc | e.col_off | g.Co) & 3) == 0 && (!e.residual || (e.ldr & 3) == 0);
-  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-  if (e.bias) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) if (n0 + j < g.Co) bias4[j] = e.bias[n0 + j];
-  }
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (n0 < g.Co && cr < CRPP) {
-#pragma unroll 2
-    for (int ps_ = 0; ps_ < CPASS; ++ps_) {
-      const int row = cr + CRPP * ps_;
-      const int m = row0 + row;
-      if (row >= BM || m >= Mrows) break;
-      int pos = m;
-      if constexpr (TCONV) {
-        int n_, d_, h_, w_;
-        decode_row(m, cnt0, cnt1, cnt2, n_, d_, h_, w_);
-        const int od = ci.o0[0] + g.sd * d_, oh = ci.o0[1] + g.sh * h_, ow = ci.o0[2] + g.sw * w_;
-        pos = ((n_ * g.Do + od) * g.Ho + oh) * g.Wo + ow;
-      }
-      const float4 c = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
-      float v[4] = {c.x + bias4[0], c.y + bias4[1], c.z + bias4[2], c.w + bias4[3]};
-      const size_t o = (size_t)pos * e.ldc + e.col_off + n0;
-      const float sc = (e.residual && e.row_scale) ? e.row_scale[pos / e.rows_per_scale] : 1.f;
-      if (vec_out) {   // Co % 4 == 0 => the whole float4 is in range
-        if (e.act_grad_src) {
-          const float4 a = ld4f(static_cast<const AT*>(e.act_grad_src) + o);
-          v[0] *= act_grad_t<BF16>(a.x, e.act_grad_kind, e.slope); v[1] *= act_grad_t<BF16>(a.y, e.act_grad_kind, e.slope);
-          v[2] *= act_grad_t<BF16>(a.z, e.act_grad_kind, e.slope); v[3] *= act_grad_t<BF16>(a.w, e.act_grad_kind, e.slope);
-        }
-        if (e.pre_act) st4f(static_cast<AT*>(e.pre_act) + o, make_float4(v[0], v[1], v[2], v[3]));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = apply_act_t<BF16>(v[j], e.act, e.slope);
-        if (e.residual) {
-          const float4 r = ld4f(static_cast<const AT*>(e.residual) + (size_t)pos * e.ldr + n0);
-          v[0] = r.x + sc * v[0]; v[1] = r.y + sc * v[1]; v[2] = r.z + sc * v[2]; v[3] = r.w + sc * v[3];
-        }
-        st4f(Y + o, make_float4(v[0], v[1], v[2], v[3]));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (n0 + j < g.Co) {
-            float t = v[j];
-            if (e.act_grad_src) t *= act_grad_t<BF16>(ldf(static_cast<const AT*>(e.act_grad_src) + o + j), e.act_grad_kind, e.slope);
-            if (e.pre_act) stf(static_cast<AT*>(e.pre_act) + o + j, t);
-            t = apply_act_t<BF16>(t, e.act, e.slope);
-            if (e.residual) t = ldf(static_cast<const AT*>(e.residual) + (size_t)pos * e.ldr + n0 + j) + sc * t;
-            stf(Y + o + j, t);
-            s1[j] += t; s2[j] += t * t;
-          }
-        }
-      }
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) load_slab(row0, col0, (kt + 1) * BK);
+      mma_slab<true, MT, NT>(As + cur * STAGE, Bs + cur * STAGE, wm * MT * 16, wn * NT * 16, lane, acc);
+      if (kt + 1 < nk) store_slab(cur ^ 1);
+      __syncthreads();
     }
-  }
-  if (e.stats) {  // per-channel sum / sumsq of what was stored: lanes sharing a column group, then the 4 waves, then ONE
-                  // double atomic per column per workgroup into one of SV_BN_SLOTS accumulator slots (spreads contention)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int o = C4; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
-    }
-    if ((lane / C4) == 0 || C4 >= 64) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { red[(wave * BN + c4 * 4 + j) * 2] = s1[j]; red[(wave * BN + c4 * 4 + j) * 2 + 1] = s2[j]; }
-    }
-    __syncthreads();
-    if (tid < BN && col0 + tid < g.Co) {
-      float a = 0.f, b = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
-      double* st = e.stats + (size_t)((row0 / BM) % SV_BN_SLOTS) * 2 * g.Co;
-      atomicAdd(st + col0 + tid, (double)a);
-      atomicAdd(st + g.Co + col0 + tid, (double)b);
-    }
+    int row0n = 0, col0n = 0;
+    const bool more = tile_of(++it, row0n, col0n);
+    if (more) load_slab(row0n, col0n, 0);                // in flight during the epilogue below
+    tile_epilogue<true, false, TL, AT>(p, ci, g.Do, g.Ho, g.Wo, Cs, red, acc, row0, col0, Mrows);
+    __syncthreads();                                     // the staged tile is consumed: operand slabs may land again
+    have = more; row0 = row0n; col0 = col0n;
   }
 }
 
@@ -768,6 +877,25 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, in
     const double e96 = est(128, 96), e64 = est(128, 64), e128 = Co > 64 ? est(128, 128) : 1e300;
     use96 = e96 <= e64 && e96 <= e128;
   }
+  // Linear / 1x1 stride-1 layers with bf16 storage: the persistent dense kernel (2 workgroups per CU walk the tiles)
+  const bool dense = !TCONV && v8 && a.g.kd * a.g.kh * a.g.kw == 1 && a.g.sd == 1 && a.g.sh == 1 && a.g.sw == 1 &&
+                     a.g.pd == 0 && a.g.ph == 0 && a.g.pw == 0 && a.g.Di == a.g.Do && a.g.Hi == a.g.Ho && a.g.Wi == a.g.Wo;
+#define SV_LAUNCH_DENSE(TL)                                                                                         \
+  do {                                                                                                              \
+    const int ntiles = cdiv(M, TL::BM) * cdiv(Co, TL::BN);                                                          \
+    int nb = 256 * (TL::NTHR >= 512 ? 2 : 4);                                                                       \
+    if (nb > ntiles) nb = ntiles;                                                                                   \
+    hipLaunchKernelGGL((gemm_dense_kernel<TL, __bf16, __bf16, 8>), dim3(nb), dim3(TL::NTHR), 0, s, a, ntiles);      \
+  } while (0)
+  if constexpr (!TCONV) {
+    if (dense && Co > 16) {
+      if (use96) SV_LAUNCH_DENSE(Tile96);
+      else if (Co > 64 && (long long)cdiv(M, 128) * cdiv(Co, 128) >= 384) SV_LAUNCH_DENSE(TileBig);
+      else SV_LAUNCH_DENSE(TileDefault);
+      return;
+    }
+  }
+#undef SV_LAUNCH_DENSE
   if (Co <= 16) {
     dim3 grid(cdiv(M, TileNarrow::BM) * cdiv(Co, TileNarrow::BN), ncls);
     SV_LAUNCH_IG(TileNarrow);
