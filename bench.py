@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--math", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--storage", default="bf16", choices=["bf16", "f32"], help="HBM element type of the activations inside the modules")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run every module on one stream (no branch / weight-gradient streams)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra untimed pass that times the engine without stream overlap")
     ap.add_argument("--detail", action="store_true", help="print the per-geometry timing table of the contraction engine to stderr")
     ap.add_argument("--cpu-views", type=int, default=8)
@@ -99,6 +100,7 @@ def main():
     hip.load()
     S.set_math(args.math)
     S.set_storage(args.storage if args.math == "bf16" else "f32")
+    S.set_overlap(not args.no_overlap)
     torch.manual_seed(1234 + rank)
     cfg = S.default_cfg()
     nets = [Encoder(cfg), Decoder(cfg), Merger(cfg), Refiner(cfg)]
@@ -155,7 +157,7 @@ def main():
             step()
         torch.cuda.synchronize()
         hip.TRACE = None
-        S.set_overlap(True)
+        S.set_overlap(not args.no_overlap)
     tmax = torch.tensor([dt], device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -17,8 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def family(name: str) -> str:
     n = name.split("(")[0]
-    if "igemm_kernel" in n or "wgrad_kernel" in n:
-        return "contraction engine (igemm_kernel + wgrad_kernel)"
+    if "igemm_kernel" in n or "wgrad_kernel" in n or "gemm_dense_kernel" in n:
+        return "contraction engine (igemm_kernel + gemm_dense_kernel + wgrad_kernel)"
     return n.replace("void ", "").strip()[-60:]
 
 
