@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import swinvox_amd as S
 from swinvox_amd import hip, ops
 from swinvox_amd.ops import ConvSpec
+if os.environ.get("SV_LIB"):
+    hip.LIB_PATH = os.environ["SV_LIB"]      # A/B builds of the library
 dev = torch.device("cuda", 0); hip.load(); S.set_math("bf16"); S.set_storage("bf16")
 def timeit(fn, iters=30):
     for _ in range(3): fn()

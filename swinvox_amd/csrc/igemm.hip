@@ -21,7 +21,10 @@
 namespace sv {
 
 constexpr int PAD_F32 = 4;   // floats
-constexpr int PAD_BF16 = 8;  // bf16     (both = 16 bytes: keeps every row 16-byte aligned)
+#ifndef SV_PAD_BF16
+#define SV_PAD_BF16 8
+#endif
+constexpr int PAD_BF16 = SV_PAD_BF16;  // bf16     (both = 16 bytes: keeps every row 16-byte aligned)
 
 struct Geom {
   int N, Di, Hi, Wi, Do, Ho, Wo, Ci, Co, kd, kh, kw, sd, sh, sw, pd, ph, pw, ldi;
