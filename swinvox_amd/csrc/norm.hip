@@ -697,6 +697,84 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_narrow_kernel(const AT* __re
   }
 }
 
+// column-group-resident variants of the two vector kernels above: a thread keeps ONE 4-channel group (gq = tid % G) and walks
+// rows (rl = tid / G, step RL = 256 / G), so the per-channel constants live in registers and the loop has no 64-bit
+// division - the generic kernels spend as many issue slots on index math and constant reloads as on the data.
+template <typename AT>
+__global__ __launch_bounds__(256) void scale_shift_act_cg_kernel(const AT* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, const AT* __restrict__ res, int ldr,
+                                                                 AT* __restrict__ y, int ldy, long long M, int C, int act, float slope,
+                                                                 long long rows_per_block, int G) {
+  const int gq = threadIdx.x % G, rl = threadIdx.x / G, RL = 256 / G;
+  const int c = (blockIdx.x * G + gq) * 4;
+  if (c >= C || rl >= RL) return;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  long long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+#pragma unroll 2
+  for (long long r = r0 + rl; r < r1; r += RL) {
+    const float4 xv = ld4f(x + (size_t)r * ldx + c);
+    float o[4] = {__fmaf_rn(xv.x, sc.x, sh.x), __fmaf_rn(xv.y, sc.y, sh.y), __fmaf_rn(xv.z, sc.z, sh.z), __fmaf_rn(xv.w, sc.w, sh.w)};
+    if (res) {
+      const float4 rv = ld4f(res + (size_t)r * ldr + c);
+      o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j], act, slope);
+    st4f(y + (size_t)r * ldy + c, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_cg_kernel(const AT* __restrict__ dz, int lddz, const AT* __restrict__ z, int ldz,
+                                                              const AT* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const double* __restrict__ sums, long long M, int C, int act, float slope,
+                                                              int training, AT* __restrict__ dx, int lddx, AT* __restrict__ dres, int lddres,
+                                                              const float* __restrict__ fsc, const float* __restrict__ fsh,
+                                                              long long rows_per_block, int G) {
+  const int gq = threadIdx.x % G, rl = threadIdx.x / G, RL = 256 / G;
+  const int c = (blockIdx.x * G + gq) * 4;
+  if (c >= C || rl >= RL) return;
+  sums += (size_t)BN_BWD_SLOTS * 2 * C;     // the folded image written by the reduce pass
+  // dx = k1*d - k2 - k3*x (double: the mean-removal terms must cancel to rounding), see bn_bwd_apply_narrow_kernel
+  double k1[4], k2[4], k3[4];
+  const double invM = 1.0 / (double)M;
+  float msc[4] = {0.f, 0.f, 0.f, 0.f}, msh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double gm = gamma[c + j], rs = rstd[c + j], mu = mean[c + j];
+    k1[j] = gm * rs;
+    if (training) { const double a = sums[c + j] * invM, b = sums[C + c + j] * invM; k3[j] = gm * rs * b * rs; k2[j] = gm * rs * a - k3[j] * mu; }
+    else { k2[j] = 0.0; k3[j] = 0.0; }
+    if (!z && act != SV_ACT_NONE) { msc[j] = fsc[c + j]; msh[j] = fsh[c + j]; }
+  }
+  const float neg = act == SV_ACT_LRELU ? slope : 0.f;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  long long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+#pragma unroll 2
+  for (long long r = r0 + rl; r < r1; r += RL) {
+    const float4 dv = ld4f(dz + (size_t)r * lddz + c), xv = ld4f(x + (size_t)r * ldx + c);
+    float d[4] = {dv.x, dv.y, dv.z, dv.w};
+    const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (act != SV_ACT_NONE) {
+      float zz[4];
+      if (z) { const float4 zv = ld4f(z + (size_t)r * ldz + c); zz[0] = zv.x; zz[1] = zv.y; zz[2] = zv.z; zz[3] = zv.w; }
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zz[j] = __fmaf_rn(xx[j], msc[j], msh[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] *= zz[j] > 0.f ? 1.f : neg;
+    }
+    if (dres) st4f(dres + (size_t)r * lddres + c, make_float4(d[0], d[1], d[2], d[3]));
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (float)(k1[j] * (double)d[j] - k2[j] - k3[j] * (double)xx[j]);
+    st4f(dx + (size_t)r * lddx + c, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
 // vector variant of pass 1 (C and the row strides multiples of 4): a thread owns 4 adjacent channels of a strided row
 // subset; G = min(C/4, 64) column groups x 256/G row lanes per workgroup, row lanes folded through LDS
 template <typename AT>
@@ -921,9 +999,13 @@ extern "C" int sv_scale_shift_act(const void* x, int ldx, const float* scale, co
     SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(scale_shift_act_narrow_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const AT*>(x), ldx, scale, shift,
                                                   static_cast<const AT*>(residual), ldr, static_cast<AT*>(y), ldy, M, C, act, slope););
   } else if (vec) {
-    long long blocks = (M * (C / 4) + 255) / 256; if (blocks > 8192) blocks = 8192;
-    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(scale_shift_act_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const AT*>(x), ldx, scale, shift,
-                                                  static_cast<const AT*>(residual), ldr, static_cast<AT*>(y), ldy, M, C, act, slope););
+    const int G = C / 4 < 64 ? C / 4 : 64, RL = 256 / G;
+    const int cg = cdiv(C / 4, G);
+    long long splits = 4096 / cg; if (splits < 1) splits = 1;
+    const long long maxs = (M + 4 * RL - 1) / (4 * RL); if (splits > maxs) splits = maxs;
+    const long long rpb = (M + splits - 1) / splits;
+    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(scale_shift_act_cg_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, static_cast<const AT*>(x), ldx, scale, shift,
+                                                  static_cast<const AT*>(residual), ldr, static_cast<AT*>(y), ldy, M, C, act, slope, rpb, G););
   } else {
     long long blocks = (M * C + 255) / 256; if (blocks > 8192) blocks = 8192;
     SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(scale_shift_act_scalar_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const AT*>(x), ldx, scale, shift,
@@ -969,9 +1051,11 @@ extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const
       hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope,
                          sums_ws, rpb, G, fsc, fsh);
       hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);
-      long long blocks = (M * (C / 4) + 255) / 256; if (blocks > 8192) blocks = 8192;
-      hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
-                         act, slope, training, dx_, lddx, dres_, lddres, dgamma, dbeta, fsc, fsh);
+      long long asplits = 4096 / cg; if (asplits < 1) asplits = 1;
+      const long long amax = (M + 4 * RL - 1) / (4 * RL); if (asplits > amax) asplits = amax;
+      const long long arpb = (M + asplits - 1) / asplits;
+      hipLaunchKernelGGL(bn_bwd_apply_cg_kernel<AT>, dim3(cg, cdiv(M, arpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
+                         act, slope, training, dx_, lddx, dres_, lddres, fsc, fsh, arpb, G);
     } else {
       const int cg = cdiv(C, 64);
       long long splits = 2048 / cg; if (splits < 1) splits = 1;
