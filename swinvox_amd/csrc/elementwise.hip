@@ -75,26 +75,33 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const AT* __restrict__ dy
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) stf(out + i, ldf(y + i) > 0.f ? ldf(dy + i) : 0.f);
 }
 
-// ---- ResNet stem max-pool 3x3 s2 p1 (NHWC); the arg-max tap is kept (first maximum in scan order, as torch)
+// ---- ResNet stem max-pool 3x3 s2 p1 (NHWC); the arg-max tap is kept (first maximum in scan order, as torch).
+// A thread owns 4 adjacent channels (8 / 16-byte accesses, one uchar4 of tap indices); C % 4 == 0.
 template <typename AT>
 __global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const AT* __restrict__ x, AT* __restrict__ y, uint8_t* __restrict__ idx,
                                                             int N, int H, int W, int C, int Ho, int Wo) {
-  const long long total = (long long)N * Ho * Wo * C;
+  const int cv = C >> 2;
+  const long long total = (long long)N * Ho * Wo * cv;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % C); long long t = i / C;
+    const int c = (int)(i % cv) * 4; long long t = i / cv;
     const int ow = (int)(t % Wo); t /= Wo; const int oh = (int)(t % Ho); const int n = (int)(t / Ho);
-    float best = -3.4e38f; int bi = 0;
+    float best[4] = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+    int bi[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
         if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-          const float v = ldf(x + (((size_t)n * H + ih) * W + iw) * C + c);
-          if (v > best) { best = v; bi = kh * 3 + kw; }
+          const float4 q = ld4f(x + (((size_t)n * H + ih) * W + iw) * C + c);
+          const float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (v[j] > best[j]) { best[j] = v[j]; bi[j] = kh * 3 + kw; }
         }
       }
-    stf(y + i, best); idx[i] = (uint8_t)bi;
+    const size_t o = (((size_t)n * Ho + oh) * Wo + ow) * C + c;
+    st4f(y + o, make_float4(best[0], best[1], best[2], best[3]));
+    *reinterpret_cast<uchar4*>(idx + o) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
   }
 }
 // gather form (no atomics, every input position written once): an input (ih, iw) belongs to the windows oh = (ih+1-kh)/2 with
@@ -102,11 +109,12 @@ __global__ __launch_bounds__(256) void maxpool2d_fwd_kernel(const AT* __restrict
 template <typename AT>
 __global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const AT* __restrict__ dy, const uint8_t* __restrict__ idx, AT* __restrict__ dx,
                                                             int N, int H, int W, int C, int Ho, int Wo) {
-  const long long total = (long long)N * H * W * C;
+  const int cv = C >> 2;
+  const long long total = (long long)N * H * W * cv;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % C); long long t = i / C;
+    const int c = (int)(i % cv) * 4; long long t = i / cv;
     const int iw = (int)(t % W); t /= W; const int ih = (int)(t % H); const int n = (int)(t / H);
-    float acc = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int kh = (ih + 1) & 1; kh < 3; kh += 2) {
       const int oh = (ih + 1 - kh) >> 1;
       if (ih + 1 - kh < 0 || oh >= Ho) continue;
@@ -114,10 +122,16 @@ __global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const AT* __restrict
         const int ow = (iw + 1 - kw) >> 1;
         if (iw + 1 - kw < 0 || ow >= Wo) continue;
         const size_t o = (((size_t)n * Ho + oh) * Wo + ow) * C + c;
-        if (idx[o] == kh * 3 + kw) acc += ldf(dy + o);
+        const uchar4 id = *reinterpret_cast<const uchar4*>(idx + o);
+        const float4 g = ld4f(dy + o);
+        const int tap = kh * 3 + kw;
+        if (id.x == tap) acc[0] += g.x;
+        if (id.y == tap) acc[1] += g.y;
+        if (id.z == tap) acc[2] += g.z;
+        if (id.w == tap) acc[3] += g.w;
       }
     }
-    stf(dx + i, acc);
+    st4f(dx + (((size_t)n * H + ih) * W + iw) * C + c, make_float4(acc[0], acc[1], acc[2], acc[3]));
   }
 }
 
@@ -525,17 +539,17 @@ extern "C" int sv_relu_bwd(const void* dy, const void* y, void* out, long long n
   return check_launch("sv_relu_bwd");
 }
 extern "C" int sv_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int act_dtype, void* stream) {
-  SV_REQUIRE(x && y && idx && N > 0 && H > 1 && W > 1 && C > 0, "maxpool2d_fwd: bad arguments");
+  SV_REQUIRE(x && y && idx && N > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0, "maxpool2d_fwd: bad arguments (C must be a multiple of 4)");
   SV_REQUIRE_ACT(act_dtype);
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(maxpool2d_fwd_kernel<AT>, dim3(grid_for((long long)N * Ho * Wo * C)), dim3(256), 0, STREAM, CA(x), MA(y), idx, N, H, W, C, Ho, Wo););
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(maxpool2d_fwd_kernel<AT>, dim3(grid_for((long long)N * Ho * Wo * (C / 4))), dim3(256), 0, STREAM, CA(x), MA(y), idx, N, H, W, C, Ho, Wo););
   return check_launch("sv_maxpool2d_fwd");
 }
 extern "C" int sv_maxpool2d_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int act_dtype, void* stream) {
-  SV_REQUIRE(dy && idx && dx && N > 0, "maxpool2d_bwd: bad arguments");
+  SV_REQUIRE(dy && idx && dx && N > 0 && C % 4 == 0, "maxpool2d_bwd: bad arguments (C must be a multiple of 4)");
   SV_REQUIRE_ACT(act_dtype);
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(maxpool2d_bwd_kernel<AT>, dim3(grid_for((long long)N * H * W * C)), dim3(256), 0, STREAM, CA(dy), idx, MA(dx), N, H, W, C, Ho, Wo););
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(maxpool2d_bwd_kernel<AT>, dim3(grid_for((long long)N * H * W * (C / 4))), dim3(256), 0, STREAM, CA(dy), idx, MA(dx), N, H, W, C, Ho, Wo););
   return check_launch("sv_maxpool2d_bwd");
 }
 extern "C" int sv_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int ldy, int col_off, int act_dtype, void* stream) {
