@@ -449,7 +449,9 @@ __global__ __launch_bounds__(256) void mean_views_kernel(const float* __restrict
 // ---- storage conversion at the module boundaries (nn.Module inputs/outputs are fp32 torch tensors)
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long long n) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (TD)(float)src[i];
+  const long long n4 = n >> 2;     // 4 elements per thread, scalar tail
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) st4f(dst + i * 4, ld4f(src + i * 4));
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (TD)(float)src[i];
 }
 
 // ---- BCE-with-logits (mean) forward + gradient in one pass (core/train.py:165,249,255)
@@ -501,7 +503,8 @@ using namespace sv;
 extern "C" int sv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream) {
   SV_REQUIRE(src && dst && n > 0, "cast: bad arguments");
   SV_REQUIRE_ACT(src_dtype); SV_REQUIRE_ACT(dst_dtype);
-  const dim3 g(grid_for(n));
+  SV_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "cast: buffers must be 16-byte aligned");
+  const dim3 g(grid_for((n + 3) / 4));
   if (src_dtype == SV_F32 && dst_dtype == SV_BF16) hipLaunchKernelGGL((cast_kernel<float, __bf16>), g, dim3(256), 0, STREAM, (const float*)src, (__bf16*)dst, n);
   else if (src_dtype == SV_BF16 && dst_dtype == SV_F32) hipLaunchKernelGGL((cast_kernel<__bf16, float>), g, dim3(256), 0, STREAM, (const __bf16*)src, (float*)dst, n);
   else if (src_dtype == SV_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, dim3(256), 0, STREAM, (const float*)src, (float*)dst, n);

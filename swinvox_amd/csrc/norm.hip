@@ -318,28 +318,38 @@ __global__ __launch_bounds__(256) void lnl_bwd_reduce_kernel(const AT* __restric
   if (threadIdx.x == 0) { atomicAdd(sums + img * 2, (double)s1); atomicAdd(sums + img * 2 + 1, (double)s2); }
 }
 
-// backward pass 2: dx per element; dw/db accumulated over the images by the thread that owns element e
+// backward pass 2: dx per element; dw/db accumulated over the images by the thread that owns elements e..e+3 (L % 4 == 0)
 template <typename AT>
 __global__ __launch_bounds__(256) void lnl_bwd_apply_kernel(const AT* __restrict__ dy, const AT* __restrict__ x,
                                                             const float* __restrict__ w, const float* __restrict__ meanrstd,
                                                             const double* __restrict__ sums, AT* __restrict__ dx,
                                                             float* __restrict__ dw, float* __restrict__ db, int L, int I,
                                                             float drop_p, uint32_t seed) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (e >= L) return;
   const float keep_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  const float wv = w[e];
-  float aw = 0.f, ab = 0.f;
+  const float4 wq = *reinterpret_cast<const float4*>(w + e);
+  const float wv[4] = {wq.x, wq.y, wq.z, wq.w};
+  float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
   for (int img = 0; img < I; ++img) {
     const float mean = meanrstd[img * 2], rstd = meanrstd[img * 2 + 1];
-    float dd = ldf(dy + (size_t)img * L + e);
-    if (drop_p > 0.f) dd = uniform01(seed, (uint64_t)img * L + e) < drop_p ? 0.f : dd * keep_inv;
-    const float xh = (ldf(x + (size_t)img * L + e) - mean) * rstd;
-    const float g = dd * wv;
-    stf(dx + (size_t)img * L + e, (float)((double)rstd * ((double)g - sums[img * 2] / L - (double)xh * (sums[img * 2 + 1] / L))));
-    aw += dd * xh; ab += dd;
+    const double m1 = sums[img * 2] / L, m2 = sums[img * 2 + 1] / L;
+    const float4 dq = ld4f(dy + (size_t)img * L + e), xq = ld4f(x + (size_t)img * L + e);
+    float dd[4] = {dq.x, dq.y, dq.z, dq.w};
+    const float xx[4] = {xq.x, xq.y, xq.z, xq.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (drop_p > 0.f) dd[j] = uniform01(seed, (uint64_t)img * L + e + j) < drop_p ? 0.f : dd[j] * keep_inv;
+      const float xh = (xx[j] - mean) * rstd;
+      const float g = dd[j] * wv[j];
+      o[j] = (float)((double)rstd * ((double)g - m1 - (double)xh * m2));
+      aw[j] += dd[j] * xh; ab[j] += dd[j];
+    }
+    st4f(dx + (size_t)img * L + e, make_float4(o[0], o[1], o[2], o[3]));
   }
-  dw[e] += aw; db[e] += ab;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { dw[e + j] += aw[j]; db[e + j] += ab[j]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -952,7 +962,7 @@ extern "C" int sv_ln_image_bwd(const void* dy, const void* x, const float* w, co
   int gx = cdiv(L, 1024); if (gx > 32) gx = 32;
   SV_DISPATCH_ACT(act_dtype,
     hipLaunchKernelGGL(lnl_bwd_reduce_kernel<AT>, dim3(gx, I), dim3(256), 0, s, static_cast<const AT*>(dy), static_cast<const AT*>(x), w, meanrstd, sums_ws, L, drop_p, seed);
-    hipLaunchKernelGGL(lnl_bwd_apply_kernel<AT>, dim3(cdiv(L, 256)), dim3(256), 0, s, static_cast<const AT*>(dy), static_cast<const AT*>(x), w, meanrstd, sums_ws,
+    hipLaunchKernelGGL(lnl_bwd_apply_kernel<AT>, dim3(cdiv(L, 1024)), dim3(256), 0, s, static_cast<const AT*>(dy), static_cast<const AT*>(x), w, meanrstd, sums_ws,
                        static_cast<AT*>(dx), dw, db, L, I, drop_p, seed););
   return check_launch("sv_ln_image_bwd");
 }
