@@ -439,7 +439,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // [q][key] in LDS and every fragment that needs 8 consecutive TOKENS per lane (P^T, dS^T, and the B operands K, Q, dO of
 // dQ / dK / dV) is produced by ds_read_b64_tr_b16, so no transposed copies exist.  15.6 KB + 9.2 KB per wave -> 4 waves.
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_a;
-constexpr int BWD16_WAVE_BYTES = (4 * 64 * LDQ_H + 64 * LDP_H) * 2 + 2 * 176 * 4;
 
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int row0, int col0, int lane) {
   // 8 consecutive rows (row0 + 8*(lane>>4) + j) of column (col0 + (lane&15)): two 4x16 transposing reads
@@ -448,196 +447,6 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int row0, 
   const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src));
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src + 4 * ld));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-template <typename AT>
-__device__ __forceinline__ void load_tile_bf16(__bf16* dst, const AT* src, int ld, int col, const TokMap& tm, int lane, float mul) {
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int r = (lane >> 3) + 8 * it, ch = (lane & 7) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < WT) v = ld4f(src + (size_t)tm.row(r) * ld + col + ch);
-    bf16x4 b;
-    b[0] = (__bf16)(v.x * mul); b[1] = (__bf16)(v.y * mul); b[2] = (__bf16)(v.z * mul); b[3] = (__bf16)(v.w * mul);
-    *reinterpret_cast<bf16x4*>(dst + r * LDQ_H + ch) = b;
-  }
-}
-
-template <typename AT>
-__global__ __launch_bounds__(256) void win_attn_bwd_bf16_kernel(const WinArgsT<AT> p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * BWD16_WAVE_BYTES];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lr = lane & 15, lg = lane >> 4;
-  const int head = blockIdx.y;
-  const int nWx = p.W / 7, nW = (p.H / 7) * nWx;
-  __bf16* Qs = reinterpret_cast<__bf16*>(smem + wave * BWD16_WAVE_BYTES);
-  __bf16* Ks = Qs + 64 * LDQ_H;
-  __bf16* Vs = Ks + 64 * LDQ_H;
-  __bf16* Ds = Vs + 64 * LDQ_H;
-  __bf16* PS = Ds + 64 * LDQ_H;
-  float* bt = reinterpret_cast<float*>(PS + 64 * LDP_H);
-  float* dbt = bt + 176;
-  for (int i = lane; i < 176; i += 64) { bt[i] = i < 169 ? p.table[i * p.heads + head] : 0.f; dbt[i] = 0.f; }
-  const int ld = 3 * p.C, colq = head * HD;
-  const long long task0 = ((long long)blockIdx.x * 4 + wave) * p.tasks_per_wave;
-
-  for (int tt = 0; tt < p.tasks_per_wave; ++tt) {
-    long long task = task0 + tt;
-    const bool active = task < p.ntasks;
-    if (!active) task = p.ntasks - 1;
-    TokMap tm;
-    tm.img = (int)(task / nW); const int win = (int)(task - (long long)tm.img * nW);
-    tm.wy = win / nWx; tm.wx = win - tm.wy * nWx; tm.H = p.H; tm.W = p.W; tm.shift = p.shift;
-
-    __syncthreads();
-    load_tile_bf16(Qs, p.qkv, ld, colq, tm, lane, p.scale);
-    load_tile_bf16(Ks, p.qkv, ld, p.C + colq, tm, lane, 1.f);
-    load_tile_bf16(Vs, p.qkv, ld, 2 * p.C + colq, tm, lane, 1.f);
-    load_tile_bf16(Ds, p.dout, p.C, colq, tm, lane, 1.f);
-    __syncthreads();
-
-    f32x4 s[4][4], dp[4][4];
-    {
-      bf16x8 a[4], b[4], c[4], d[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int off = (t * 16 + lr) * LDQ_H + lg * 8;
-        a[t] = *reinterpret_cast<const bf16x8*>(Qs + off); b[t] = *reinterpret_cast<const bf16x8*>(Ks + off);
-        c[t] = *reinterpret_cast<const bf16x8*>(Ds + off); d[t] = *reinterpret_cast<const bf16x8*>(Vs + off);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          s[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          dp[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c[mt], d[nt], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        }
-    }
-    bias_mask_softmax(s, bt, tm, lane, p.shift > 0);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float r = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) r += dp[mt][nt][j] * s[mt][nt][j];
-        r = group16_sum(r);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) dp[mt][nt][j] = s[mt][nt][j] * (dp[mt][nt][j] - r);
-      }
-    if (active) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int q = mt * 16 + lg * 4 + j;
-          if (q < WT) {
-            const int qy = q / 7, qx = q - qy * 7;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-              const int key = nt * 16 + lr;
-              if (key < WT) {
-                const int ky = key / 7, kx = key - ky * 7;
-                atomicAdd(dbt + (qy - ky + 6) * 13 + (qx - kx + 6), dp[mt][nt][j]);
-              }
-            }
-          }
-        }
-    }
-    // ---- dV = P^T dO
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) PS[(mt * 16 + lg * 4 + j) * LDP_H + nt * 16 + lr] = (__bf16)s[mt][nt][j];
-    __syncthreads();
-    {
-      f32x4 acc[4][2];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 a[4], b[2];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a[mt] = tr_frag(PS, LDP_H, ks * 32, mt * 16, lane);   // A[key][q]
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) b[nt] = tr_frag(Ds, LDQ_H, ks * 32, nt * 16, lane);   // B[q][d]
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
-      }
-      if (active) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int key = mt * 16 + lg * 4 + j;
-            if (key < WT) {
-              AT* dst = p.dqkv + (size_t)tm.row(key) * ld + 2 * p.C + colq;
-              stf(dst + lr, acc[mt][0][j]); stf(dst + 16 + lr, acc[mt][1][j]);
-            }
-          }
-      }
-    }
-    __syncthreads();
-    // ---- dQ = scale * dS K ; dK = dS^T (scale*Q)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) PS[(mt * 16 + lg * 4 + j) * LDP_H + nt * 16 + lr] = (__bf16)dp[mt][nt][j];
-    __syncthreads();
-    {
-      f32x4 aq[4][2], ak[4][2];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        aq[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; aq[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        ak[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; ak[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 a1[4], a2[4], b1[2], b2[2];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          a1[mt] = *reinterpret_cast<const bf16x8*>(PS + (mt * 16 + lr) * LDP_H + ks * 32 + lg * 8);   // dS[q][key], key contiguous
-          a2[mt] = tr_frag(PS, LDP_H, ks * 32, mt * 16, lane);                                          // dS^T[key][q]
-        }
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          b1[nt] = tr_frag(Ks, LDQ_H, ks * 32, nt * 16, lane);   // K[key][d]
-          b2[nt] = tr_frag(Qs, LDQ_H, ks * 32, nt * 16, lane);   // (scale*Q)[q][d]
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            aq[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b1[nt], aq[mt][nt], 0, 0, 0);
-            ak[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b2[nt], ak[mt][nt], 0, 0, 0);
-          }
-      }
-      if (active) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int t = mt * 16 + lg * 4 + j;
-            if (t < WT) {
-              AT* dst = p.dqkv + (size_t)tm.row(t) * ld + colq;
-              stf(dst + lr, aq[mt][0][j] * p.scale); stf(dst + 16 + lr, aq[mt][1][j] * p.scale);
-              stf(dst + p.C + lr, ak[mt][0][j]); stf(dst + p.C + 16 + lr, ak[mt][1][j]);
-            }
-          }
-      }
-    }
-  }
-  __syncthreads();
-  for (int i = lane; i < 169; i += 64) {
-    const float v = dbt[i];
-    if (v != 0.f) atomicAdd(p.dtable + i * p.heads + head, v);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -61,7 +61,6 @@ template <int WM_, int WN_, int MT_, int NT_> struct Tile {
   static constexpr int NW = WM_ * WN_, NTHR = NW * 64;
 };
 typedef Tile<4, 2, 2, 2> TileDefault;   // 128 x 64, 8 waves of 32x32 (few registers per thread -> 2-3 workgroups per CU)
-typedef Tile<2, 2, 4, 4> TileWide;      // 128 x 128, 4 waves (register-heavy: measured slower, kept for reference)
 typedef Tile<2, 4, 4, 2> TileBig;       // 128 x 128, 8 waves (512 threads): halves the A re-reads of TileDefault at equal registers
 typedef Tile<4, 1, 2, 1> TileNarrow;    // 128 x 16
 typedef Tile<4, 2, 2, 3> Tile96;        // 128 x 96, 8 waves: the Swin channel counts are multiples of 96 (no padded columns for 96 / 192 / 288)

@@ -401,28 +401,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   save_mean[c] = mean; save_rstd[c] = rstd;
 }
 
-// y = act(x*scale[c] + shift[c] (+ residual))
-template <typename AT>
-__global__ __launch_bounds__(256) void scale_shift_act_kernel(const AT* __restrict__ x, int ldx, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, const AT* __restrict__ res,
-                                                              int ldr, AT* __restrict__ y, int ldy, long long M, int C,
-                                                              int act, float slope) {
-  const int cv = C >> 2;  // C % 4 == 0 path
-  const long long total = M * cv;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / cv; const int c = (int)(i - r * cv) * 4;
-    const float4 xv = ld4f(x + (size_t)r * ldx + c);
-    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
-    float o[4] = {__fmaf_rn(xv.x, sc.x, sh.x), __fmaf_rn(xv.y, sc.y, sh.y), __fmaf_rn(xv.z, sc.z, sh.z), __fmaf_rn(xv.w, sc.w, sh.w)};
-    if (res) {
-      const float4 rv = ld4f(res + (size_t)r * ldr + c);
-      o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j], act, slope);
-    st4f(y + (size_t)r * ldy + c, make_float4(o[0], o[1], o[2], o[3]));
-  }
-}
+// y = act(x*scale[c] + shift[c] (+ residual)): scalar fallback (any C / strides); the vector paths are the *_cg and *_narrow kernels below
 template <typename AT>
 __global__ __launch_bounds__(256) void scale_shift_act_scalar_kernel(const AT* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                                      const float* __restrict__ shift, const AT* __restrict__ res,
@@ -524,52 +503,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const AT* __restrict_
       o = d * gamma[c] * rs;
     }
     stf(dx + (size_t)r * lddx + c, o);
-  }
-}
-
-// 16-byte variant of the above (C and every row stride multiples of 4): 4 channels per thread
-template <typename AT>
-__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const AT* __restrict__ dz, int lddz, const AT* __restrict__ z, int ldz,
-                                                               const AT* __restrict__ x, int ldx, const float* __restrict__ gamma,
-                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                               const double* __restrict__ sums, long long M, int C, int act, float slope,
-                                                               int training, AT* __restrict__ dx, int lddx, AT* __restrict__ dres,
-                                                               int lddres, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               const float* __restrict__ fsc, const float* __restrict__ fsh) {
-  const int cv = C >> 2;
-  const long long total = M * cv;
-  const double invM = 1.0 / (double)M;
-  sums += (size_t)BN_BWD_SLOTS * 2 * C;     // the folded image written by the reduce pass
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / cv; const int c = (int)(i - r * cv) * 4;
-    const float4 dv = ld4f(dz + (size_t)r * lddz + c);
-    float d[4] = {dv.x, dv.y, dv.z, dv.w};
-    const float4 xv = ld4f(x + (size_t)r * ldx + c);
-    const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
-    if (act != SV_ACT_NONE) {
-      float zz[4];
-      if (z) { const float4 zv = ld4f(z + (size_t)r * ldz + c); zz[0] = zv.x; zz[1] = zv.y; zz[2] = zv.z; zz[3] = zv.w; }
-      else {   // no saved output: recompute the pre-activation exactly as the forward did
-        const float4 sc = *reinterpret_cast<const float4*>(fsc + c), sh = *reinterpret_cast<const float4*>(fsh + c);
-        zz[0] = __fmaf_rn(xx[0], sc.x, sh.x); zz[1] = __fmaf_rn(xx[1], sc.y, sh.y); zz[2] = __fmaf_rn(xx[2], sc.z, sh.z); zz[3] = __fmaf_rn(xx[3], sc.w, sh.w);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) d[j] *= (zz[j] > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
-    }
-    if (dres) st4f(dres + (size_t)r * lddres + c, make_float4(d[0], d[1], d[2], d[3]));
-    float o[4];
-    if (training) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const double rs = (double)rstd[c + j];
-        const double xh = ((double)xx[j] - (double)mean[c + j]) * rs;
-        o[j] = (float)((double)gamma[c + j] * rs * ((double)d[j] - sums[c + j] * invM - xh * (sums[C + c + j] * invM)));
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = d[j] * gamma[c + j] * rstd[c + j];
-    }
-    st4f(dx + (size_t)r * lddx + c, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
@@ -707,9 +640,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_narrow_kernel(const AT* __re
   }
 }
 
-// column-group-resident variants of the two vector kernels above: a thread keeps ONE 4-channel group (gq = tid % G) and walks
-// rows (rl = tid / G, step RL = 256 / G), so the per-channel constants live in registers and the loop has no 64-bit
-// division - the generic kernels spend as many issue slots on index math and constant reloads as on the data.
+// vector paths of BatchNorm apply / backward apply (C and every row stride multiples of 4): a thread keeps ONE 4-channel group
+// (gq = tid % G) and walks rows (rl = tid / G, step RL = 256 / G), so the per-channel constants live in registers and the loop
+// has no 64-bit division (a flat element loop spends as many issue slots on index math and constant reloads as on the data).
 template <typename AT>
 __global__ __launch_bounds__(256) void scale_shift_act_cg_kernel(const AT* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, const AT* __restrict__ res, int ldr,
