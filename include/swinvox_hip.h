@@ -221,6 +221,19 @@ int sv_mean_views(const float* vol, float* out, int B, int V, int S, void* strea
 int sv_bce_logits(const float* x, const float* t, long long n, float* loss_accum, float* dx, const float* gscale_dev, void* stream); /* core/train.py:165,249,255 */
 int sv_iou_counts(const float* logits, const float* gt, const float* thresholds_dev, int nth, int B, int S, float* counts, void* stream); /* core/test.py:141-153 */
 
+/* Optimiser step on one flat fp32 buffer per module (parameters, gradients and moments share one layout).
+ *  sv_grad_sumsq: slots16[blockIdx & 15] += sum (g * gscale)^2 in double; the caller zeroes the 16 slots.  It is the squared
+ *    L2 norm torch.nn.utils.clip_grad_norm_ takes over a module's gradients (core/train.py:279-282).
+ *  sv_adam_step / sv_sgd_step: torch.optim.Adam (coupled L2 weight decay, no amsgrad) / torch.optim.SGD (momentum) as
+ *    configured at core/train.py:98-131 and stepped at :287-292.  Every gradient is first multiplied by
+ *    gscale * min(1, max_norm / (sqrt(sum slots16) + 1e-6)) - the data-parallel mean and the clip coefficient, read on the
+ *    device; slots16 == NULL or max_norm <= 0 disables clipping.  `step` counts from 1 (bias correction).            */
+int sv_grad_sumsq(const float* g, long long n, float gscale, double* slots16, void* stream);
+int sv_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
+                 double weight_decay, long long step, float gscale, const double* slots16, float max_norm, void* stream);
+int sv_sgd_step(float* p, const float* g, float* momentum_buf, long long n, double lr, double momentum, double weight_decay,
+                int first_step, float gscale, const double* slots16, float max_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,8 @@ import torch
 import torch.distributed as dist
 from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 
+from .optim import flat_region
+
 
 class GradAllReducer:
     def __init__(self, modules: Sequence[torch.nn.Module], bucket_bytes: int = 64 << 20, group=None):
@@ -49,7 +51,11 @@ class GradAllReducer:
 
     def _launch(self, bi: int):
         grads = [p.grad for p in self.buckets[bi]]
-        flat = _flatten_dense_tensors(grads)
+        flat = flat_region(grads)          # a HipModule's gradients are views of one buffer: reduce it in place
+        if flat is not None:
+            grads = None
+        else:
+            flat = _flatten_dense_tensors(grads)
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((work, flat, grads))
 
@@ -69,8 +75,9 @@ class GradAllReducer:
         for work, flat, grads in self._pending:
             work.wait()
             flat.div_(self.world)
-            for g, r in zip(grads, _unflatten_dense_tensors(flat, grads)):
-                g.copy_(r)
+            if grads is not None:
+                for g, r in zip(grads, _unflatten_dense_tensors(flat, grads)):
+                    g.copy_(r)
         self._reset()
 
     def remove(self):

@@ -7,8 +7,9 @@
   evaluate(...)    = core/test.py:114-153 for a batch: fp32-style eval forward, losses x10, sigmoid-threshold IoU at
                      cfg.TEST.VOXEL_THRESH computed on the device (sv_iou_counts), one host sync for the whole batch.
   make_solvers(...) = core/train.py:98-152 (Adam with the reference betas / weight decay / per-module learning rates,
-                     or SGD), MultiStepLR schedulers.
-Everything outside the model forward/backward is stock PyTorch (optimizers, clipping): plumbing, not the hot path.
+                     or SGD), MultiStepLR schedulers; by default the flat-buffer solvers of optim.py, which fuse the
+                     per-module clip_grad_norm_(1.0) into the update (two launches per module).
+  checkpoint_dict / load_checkpoint = core/train.py:347-369 / :163-190 (same keys, `module.` prefixes accepted).
 """
 from __future__ import annotations
 
@@ -18,21 +19,26 @@ import torch
 
 from . import hip
 from .hip import call, ptr
+from .optim import FlatAdam, FlatSGD, _FlatSolver
 
 _bce = torch.nn.functional.binary_cross_entropy_with_logits
 
 
-def make_solvers(nets, cfg):
+def make_solvers(nets, cfg, fused: bool = True):
+    """fused=True: optim.FlatAdam / FlatSGD (clip + step in two launches per module); False: the stock torch optimizers."""
     enc, dec, mer, ref = nets
     t = cfg.TRAIN
     lrs = (t.ENCODER_LEARNING_RATE, t.DECODER_LEARNING_RATE, t.MERGER_LEARNING_RATE, t.REFINER_LEARNING_RATE)
     mods = (enc, dec, mer, ref)
     if t.POLICY == "adam":
-        opts = [torch.optim.Adam(m.parameters(), lr=lr, betas=tuple(t.BETAS), weight_decay=t.WEIGHT_DECAY) for m, lr in zip(mods, lrs)]
+        mk = (lambda ps, lr: FlatAdam(ps, lr=lr, betas=tuple(t.BETAS), weight_decay=t.WEIGHT_DECAY)) if fused else \
+             (lambda ps, lr: torch.optim.Adam(ps, lr=lr, betas=tuple(t.BETAS), weight_decay=t.WEIGHT_DECAY))
     elif t.POLICY == "sgd":
-        opts = [torch.optim.SGD(m.parameters(), lr=lr, momentum=t.MOMENTUM, weight_decay=t.WEIGHT_DECAY) for m, lr in zip(mods, lrs)]
+        mk = (lambda ps, lr: FlatSGD(ps, lr=lr, momentum=t.MOMENTUM, weight_decay=t.WEIGHT_DECAY)) if fused else \
+             (lambda ps, lr: torch.optim.SGD(ps, lr=lr, momentum=t.MOMENTUM, weight_decay=t.WEIGHT_DECAY))
     else:
         raise Exception("[FATAL] Unknown optimizer %s." % t.POLICY)   # reference core/train.py:133
+    opts = [mk([p for p in m.parameters() if p.requires_grad], lr) for m, lr in zip(mods, lrs)]
     ms = (t.ENCODER_LR_MILESTONES, t.DECODER_LR_MILESTONES, t.MERGER_LR_MILESTONES, t.REFINER_LR_MILESTONES)
     scheds = [torch.optim.lr_scheduler.MultiStepLR(o, milestones=list(m), gamma=t.GAMMA) for o, m in zip(opts, ms)]
     return opts, scheds
@@ -85,17 +91,19 @@ def train_step(nets, solvers, cfg, images, gt, epoch_idx: int = 0, reducer=None)
     total.backward()
     if reducer is not None:
         reducer.finish()
-    for n in nets:
-        ps = [p for p in n.parameters() if p.grad is not None]
-        if ps:
-            torch.nn.utils.clip_grad_norm_(ps, max_norm=1.0)
     enc_s, dec_s, mer_s, ref_s = solvers
-    enc_s.step()
-    dec_s.step()
-    if use_refiner:
-        ref_s.step()
-    if use_merger:
-        mer_s.step()
+    active = [(nets[0], enc_s, True), (nets[1], dec_s, True), (nets[3], ref_s, use_refiner), (nets[2], mer_s, use_merger)]
+    for n, sol, _ in active:                         # clip every module (core/train.py:279-282) ...
+        if not isinstance(sol, _FlatSolver):
+            ps = [p for p in n.parameters() if p.grad is not None]
+            if ps:
+                torch.nn.utils.clip_grad_norm_(ps, max_norm=1.0)
+    for n, sol, on in active:                        # ... then step in the reference order (:287-292)
+        if on:
+            if isinstance(sol, _FlatSolver):
+                sol.step(clip_norm=1.0)              # norm + clip + update fused on the flat buffers
+            else:
+                sol.step()
     return el.detach(), rl.detach()
 
 
@@ -111,3 +119,46 @@ def evaluate(nets, cfg, images, gt, epoch_idx: int = 0):
     inter, union = counts[..., 0], counts[..., 1]
     iou = torch.where(union > 0, inter / union.clamp_min(1), torch.ones_like(inter))
     return el * 10, rl * 10, iou
+
+
+_SCALER_STATE = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0}
+
+
+def checkpoint_dict(nets, cfg, epoch_idx: int, best_iou: float, best_epoch: int, module_prefix: bool = True):
+    """The dict core/train.py:347-369 saves.  The reference checkpoints DataParallel-wrapped modules on a GPU machine, so its
+    keys carry a `module.` prefix; module_prefix=True writes the same keys so that core/test.py:81-90 and the resume path
+    core/train.py:171-186 load the file unchanged.  Tensors are cloned (parameters may be views of a solver's flat buffer).
+    `scaler_state_dict` holds the state of an untouched GradScaler(init_scale=2**16): there is no loss scaling here."""
+    enc, dec, mer, ref = nets
+    pre = "module." if module_prefix else ""
+
+    def sd(m):
+        return {pre + k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    ck = {"epoch_idx": int(epoch_idx), "best_iou": float(best_iou), "best_epoch": int(best_epoch),
+          "encoder_state_dict": sd(enc), "decoder_state_dict": sd(dec), "scaler_state_dict": dict(_SCALER_STATE)}
+    if cfg.NETWORK.USE_REFINER:
+        ck["refiner_state_dict"] = sd(ref)
+    if cfg.NETWORK.USE_MERGER:
+        ck["merger_state_dict"] = sd(mer)
+    return ck
+
+
+def load_checkpoint(nets, cfg, checkpoint):
+    """Counterpart of core/train.py:171-186 / core/test.py:81-90: `checkpoint` is a path (read with weights_only=True) or an
+    already loaded dict; keys with or without the DataParallel `module.` prefix are accepted.  Parameters are copied in place
+    (flat-solver views stay valid).  Returns (epoch_idx, best_iou, best_epoch)."""
+    if not isinstance(checkpoint, dict):
+        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=True)
+    enc, dec, mer, ref = nets
+
+    def strip(sd):
+        return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+    enc.load_state_dict(strip(checkpoint["encoder_state_dict"]))
+    dec.load_state_dict(strip(checkpoint["decoder_state_dict"]))
+    if cfg.NETWORK.USE_REFINER:
+        ref.load_state_dict(strip(checkpoint["refiner_state_dict"]))
+    if cfg.NETWORK.USE_MERGER:
+        mer.load_state_dict(strip(checkpoint["merger_state_dict"]))
+    return checkpoint["epoch_idx"], checkpoint.get("best_iou", -1), checkpoint.get("best_epoch", -1)

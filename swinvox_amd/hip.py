@@ -38,7 +38,7 @@ class PackDesc(C.Structure):   # sv_pack_desc
 
 
 # name -> (restype, argtypes); p = device/host pointer, i = int, l = long long, f = float, u = uint32, z = size_t
-_P, _I, _L, _F, _U = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint32
+_P, _I, _L, _F, _U, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint32, C.c_double
 # Entry points whose activation tensors are void* + `int act_dtype` (inserted by call() right before the stream argument)
 _ACT_TYPED = {
     "sv_conv_gather", "sv_tconv_gather", "sv_conv_wgrad", "sv_stencil3_fwd", "sv_stencil3_wgrad", "sv_colsum",
@@ -106,6 +106,9 @@ _PROTOS = {
     "sv_mean_views": (_I, [_P, _P, _I, _I, _I]),
     "sv_bce_logits": (_I, [_P, _P, _L, _P, _P, _P]),
     "sv_iou_counts": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "sv_grad_sumsq": (_I, [_P, _L, _F, _P]),
+    "sv_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _L, _F, _P, _F]),
+    "sv_sgd_step": (_I, [_P, _P, _P, _L, _D, _D, _D, _I, _F, _P, _F]),
 }
 
 

@@ -18,16 +18,18 @@ from ..ops import ACT_LRELU, ACT_NONE, ACT_RELU, BatchNormState, ConvSpec, call,
 
 
 class GradStore:
-    """Zero-initialised gradient accumulators for every parameter of a module (one flat buffer)."""
+    """Zero-initialised gradient accumulators for every parameter of a module: views of one flat buffer in the FlatLayout
+    of the parameter list (optim.py), so that a flat solver / the gradient all-reduce can take the buffer in place."""
 
-    def __init__(self, params: Sequence[torch.Tensor]):
+    def __init__(self, params: Sequence[torch.Tensor], layout=None):
+        from ..optim import FlatLayout
         self.params = list(params)
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(max(total, 4), dtype=torch.float32, device=self.params[0].device) if self.params else None
         self._map: Dict[int, torch.Tensor] = {}
-        if self.params:   # one C++ call makes every parameter-shaped view of the flat buffer
-            views = torch._utils._unflatten_dense_tensors(self.flat[:total], self.params)
-            for p, v in zip(self.params, views):
+        self.flat = None
+        if self.params:
+            layout = layout if layout is not None else FlatLayout(self.params)
+            self.flat = torch.zeros(layout.total, dtype=torch.float32, device=self.params[0].device)
+            for p, v in zip(self.params, layout.views(self.flat)):   # one C++ call cuts every parameter-shaped view
                 self._map[id(p)] = v
 
     def __getitem__(self, p: torch.Tensor) -> torch.Tensor:
@@ -64,7 +66,7 @@ class _ModuleFn(torch.autograd.Function):
         mod = ctx.mod
         if ctx.tape is None:
             raise RuntimeError("swinvox_amd: backward requested but the forward ran without a tape (no_grad?)")
-        grads = GradStore(mod._param_list())
+        grads = GradStore(mod._param_list(), mod._grad_layout())
         if ops.get_storage() != ctx.store:
             raise RuntimeError("swinvox_amd: set_storage() changed between forward and backward")
         ops.set_pack_cache(mod.__dict__.setdefault("_packs", ops.PackCache()))
@@ -100,6 +102,14 @@ class HipModule(nn.Module):
             pl = list(self.parameters())
             self.__dict__["_plist"], self.__dict__["_plist_n"] = pl, len(pl)
         return pl
+
+    def _grad_layout(self):
+        from ..optim import FlatLayout
+        pl = self._param_list()
+        lay = self.__dict__.get("_glayout")
+        if lay is None or not lay.matches(pl):
+            lay = self.__dict__["_glayout"] = FlatLayout(pl)
+        return lay
 
     def _run(self, *inputs):
         hip.check_cuda(*inputs)

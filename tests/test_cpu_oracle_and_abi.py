@@ -141,12 +141,12 @@ def test_ctypes_prototypes_match_the_header():
             return None
         if "*" in a:
             return "P"
-        for key, c in (("long long", "L"), ("uint32_t", "U"), ("float", "F"), ("int", "I")):
+        for key, c in (("long long", "L"), ("uint32_t", "U"), ("double", "D"), ("float", "F"), ("int", "I")):
             if key in a:
                 return c
         raise AssertionError(a)
 
-    cmap = {ctypes.c_void_p: "P", ctypes.c_int: "I", ctypes.c_longlong: "L", ctypes.c_float: "F", ctypes.c_uint32: "U"}
+    cmap = {ctypes.c_void_p: "P", ctypes.c_int: "I", ctypes.c_longlong: "L", ctypes.c_float: "F", ctypes.c_uint32: "U", ctypes.c_double: "D"}
     for name, args in protos:
         want = [c for c in (code(a) for a in args.split(",")) if c]
         got = [cmap.get(t, "P") for t in hip._argtypes(name)]

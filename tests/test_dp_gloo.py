@@ -62,6 +62,16 @@ def _worker(rank, world, port, q):
     out = {f"{i}.{k}": p.grad.numpy().copy() for i, n in enumerate(nets) for k, p in n.named_parameters()}
     if rank == 0:
         q.put(out)
+    # gradients that are views of one flat buffer (what a HipModule's backward returns) are reduced in place
+    from swinvox_amd.optim import FlatLayout
+    lin = torch.nn.Linear(5, 3)
+    red2 = GradAllReducer([lin])
+    lay = FlatLayout(list(lin.parameters()))
+    flat = torch.full((lay.total,), float(rank + 1))
+    for p, v in zip(lin.parameters(), lay.views(flat)):
+        p.grad = v
+    red2.finish()
+    assert lin.weight.grad.data_ptr() == flat.data_ptr() and all(bool((p.grad == 1.5).all()) for p in lin.parameters())
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,0 +1,124 @@
+"""Flat-buffer solvers (swinvox_amd/optim.py: sv_grad_sumsq + sv_adam_step / sv_sgd_step) against the reference's
+clip_grad_norm_(1.0) + torch.optim.Adam / SGD sequence (core/train.py:98-131, :279-292) on the same gradients."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O  # noqa: E402
+import swinvox_amd as S  # noqa: E402
+from swinvox_amd import harness, hip  # noqa: E402
+from swinvox_amd.models import Decoder, Encoder, Merger, Refiner  # noqa: E402
+from swinvox_amd.optim import FlatAdam, FlatLayout, FlatSGD  # noqa: E402
+
+
+def _pair(dev):
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Conv3d(3, 5, 3), torch.nn.BatchNorm1d(7), torch.nn.Linear(1, 1)).to(dev)
+    return a, copy.deepcopy(a)
+
+
+def _set_grads(a, b, step, scale, flat_views):
+    g = torch.Generator().manual_seed(100 + step)
+    lay = FlatLayout(list(a.parameters()))
+    gflat = torch.zeros(lay.total, device=next(a.parameters()).device)
+    views = lay.views(gflat)
+    for pa, pb, v in zip(a.parameters(), b.parameters(), views):
+        gr = (scale * torch.randn(pa.shape, generator=g)).to(pa.device)
+        v.copy_(gr)
+        pa.grad = v if flat_views else gr.clone()      # in-place path (views of one buffer) or the gather path
+        pb.grad = gr.clone()
+    return gflat
+
+
+@pytest.mark.parametrize("flat_views", [True, False])
+@pytest.mark.parametrize("scale", [3.0, 1e-3])           # clipped (norm >> 1) and unclipped (norm << 1)
+def test_flat_adam_matches_clip_plus_torch_adam(dev, flat_views, scale):
+    a, b = _pair(dev)
+    kw = dict(lr=1e-2, betas=(0.85, 0.993), weight_decay=3.37e-4)      # reference config.py:111-122 betas / weight decay
+    fa = FlatAdam(a.parameters(), **kw)
+    tb = torch.optim.Adam(b.parameters(), **kw)
+    assert all(p.data_ptr() == fa.flat_p.data_ptr() + 4 * o for p, o in zip(a.parameters(), fa.layout.offsets))
+    for step in range(4):
+        _set_grads(a, b, step, scale, flat_views)
+        norm = torch.nn.utils.clip_grad_norm_(list(b.parameters()), max_norm=1.0)
+        tb.step()
+        fa.step(clip_norm=1.0)
+        assert float((fa.grad_norm() - norm).abs()) <= 1e-5 * float(norm)
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert float((pa - pb).abs().max()) <= 2e-6 * max(1.0, float(pb.abs().max())), step
+    sd = fa.state_dict()
+    fa2 = FlatAdam(copy.deepcopy(a).parameters(), **kw)
+    fa2.load_state_dict(sd)
+    assert fa2.steps == 4 and torch.equal(fa2.exp_avg, fa.exp_avg) and torch.equal(fa2.exp_avg_sq, fa.exp_avg_sq)
+
+
+def test_flat_sgd_and_scheduler_and_grad_scale(dev):
+    a, b = _pair(dev)
+    fs = FlatSGD(a.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3)
+    ts = torch.optim.SGD(b.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3)
+    sa = torch.optim.lr_scheduler.MultiStepLR(fs, milestones=[2], gamma=0.5)
+    sb = torch.optim.lr_scheduler.MultiStepLR(ts, milestones=[2], gamma=0.5)
+    for step in range(4):
+        _set_grads(a, b, step, 2.0, True)
+        for p in b.parameters():
+            p.grad.mul_(0.5)                                  # the data-parallel 1/world the flat step folds in as grad_scale
+        torch.nn.utils.clip_grad_norm_(list(b.parameters()), max_norm=1.0)
+        ts.step()
+        fs.step(clip_norm=1.0, grad_scale=0.5)
+        sa.step()
+        sb.step()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert float((pa - pb).abs().max()) <= 2e-6 * max(1.0, float(pb.abs().max())), step
+    assert fs.param_groups[0]["lr"] == ts.param_groups[0]["lr"] == 0.025
+
+
+def test_flat_solver_edge_cases(dev):
+    a, _ = _pair(dev)
+    fa = FlatAdam(a.parameters(), lr=1e-2)
+    before = fa.flat_p.clone()
+    fa.step(clip_norm=1.0)                                    # no gradients at all: nothing happens (module gated off this epoch)
+    assert fa.steps == 0 and torch.equal(before, fa.flat_p)
+    next(a.parameters()).grad = torch.zeros_like(next(a.parameters()))
+    with pytest.raises(RuntimeError, match="some parameters"):
+        fa.step()
+    a.zero_grad(set_to_none=True)
+    a.to("cpu").to(dev)                                       # parameters re-allocated behind the solver's back -> re-adopted
+    _set_grads(a, a, 0, 1.0, True)
+    fa.step()
+    assert fa.layout.locate([p.data for p in a.parameters()]) == fa.flat_p.data_ptr()
+    lib = hip.load()
+    assert lib.sv_adam_step(fa.flat_p.data_ptr() + 4, 0, 0, 0, 16, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None, 0.0, None) != 0
+    assert b"adam_step" in lib.sv_last_error()
+
+
+def test_train_step_with_flat_solvers_matches_stock_solvers(dev):
+    """Whole train_step (core/train.py:222-297): the HipModule backward hands its gradient buffer to the flat solver in place;
+    after two steps the parameters equal those of the clip_grad_norm_ + torch.optim.Adam sequence on a twin model."""
+    cfg = S.default_cfg()
+    nets_a = [Encoder(cfg), Decoder(cfg), Merger(cfg), Refiner(cfg)]
+    for i, n in enumerate(nets_a):
+        O.seeded_weights_(n, seed=7 + i)
+        n.stochastic = False
+    nets_b = copy.deepcopy(nets_a)
+    for n in nets_a + nets_b:
+        n.to(dev).train()
+    sol_a, _ = harness.make_solvers(nets_a, cfg, fused=True)
+    sol_b, _ = harness.make_solvers(nets_b, cfg, fused=False)
+    g = torch.Generator().manual_seed(3)
+    x = (0.5 * torch.randn(2, 2, 3, 224, 224, generator=g)).to(dev)
+    gt = (torch.rand(2, 32, 32, 32, generator=g) < 0.1).float().to(dev)
+    for step in range(2):
+        la = harness.train_step(nets_a, sol_a, cfg, x, gt)
+        lb = harness.train_step(nets_b, sol_b, cfg, x, gt)
+        assert float((la[0] - lb[0]).abs()) < 1e-4 and float((la[1] - lb[1]).abs()) < 1e-4
+        if step == 0:     # the solver read the backward's buffer in place (no gather copy was ever allocated)
+            assert all(s._gflat is None for s in sol_a)
+    worst = 0.0
+    for na, nb in zip(nets_a, nets_b):
+        for (k, pa), pb in zip(na.named_parameters(), nb.parameters()):
+            worst = max(worst, float((pa - pb).abs().max()) / max(1e-3, float(pb.abs().max())))
+    # step 2 starts from parameters that agree to ~1e-7; atomics in the weight-gradient kernels reorder sums between runs
+    assert worst < 5e-3, worst
