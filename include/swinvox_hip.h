@@ -219,7 +219,7 @@ int sv_merge_views_bwd(const void* wlogit, const void* vol, const void* out, con
 /* harness-side kernels on fp32 module outputs */
 int sv_mean_views(const float* vol, float* out, int B, int V, int S, void* stream);                      /* core/train.py:246 */
 int sv_bce_logits(const float* x, const float* t, long long n, float* loss_accum, float* dx, const float* gscale_dev, void* stream); /* core/train.py:165,249,255 */
-int sv_iou_counts(const float* logits, const float* gt, const float* thresholds_dev, int nth, int B, int S, float* counts, void* stream); /* core/test.py:141-153 */
+int sv_iou_counts(const float* logits, const float* gt, const float* thresholds_dev, int nth, int B, int S, float* counts, void* stream); /* core/test.py:141-163: counts[B][nth][4] = {intersection = TP, union, FP, FN} of sigmoid(logits) >= th vs gt, nth <= 8 */
 
 /* Optimiser step on one flat fp32 buffer per module (parameters, gradients and moments share one layout).
  *  sv_grad_sumsq: slots16[blockIdx & 15] += sum (g * gscale)^2 in double; the caller zeroes the 16 slots.  It is the squared

@@ -23,5 +23,5 @@ Pinning status (see DESIGN.md "Oracle"):
 from .model import (  # noqa: F401
     Cfg, default_cfg, Encoder, Decoder, Merger, Refiner, SwinTransformer,
     CrossViewAttention, SwinBackbone, ResNetTrunk, init_weights, calibrate_,
-    seeded_weights_, bce_logits, iou_at_thresholds, train_step_loss,
+    seeded_weights_, bce_logits, iou_at_thresholds, fscore_at_thresholds, train_step_loss,
 )

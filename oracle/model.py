@@ -567,6 +567,25 @@ def iou_at_thresholds(logits: torch.Tensor, gt: torch.Tensor, ths=(0.2, 0.3, 0.4
     return out
 
 
+def fscore_at_thresholds(logits: torch.Tensor, gt: torch.Tensor, ths=(0.2, 0.3, 0.4, 0.5)) -> List[List[float]]:
+    """Per-sample F1 per threshold from TP / FP / FN of the thresholded occupancy, with the reference's 1e-8 epsilons
+    (core/test.py:155-163)."""
+    p = torch.sigmoid(logits)
+    out = []
+    for b in range(p.shape[0]):
+        row = []
+        for th in ths:
+            v = (p[b] >= th).float()
+            tp = (v * gt[b]).sum().float()
+            fp = (v * (1 - gt[b])).sum().float()
+            fn = ((1 - v) * gt[b]).sum().float()
+            precision = tp / (tp + fp + 1e-8)
+            recall = tp / (tp + fn + 1e-8)
+            row.append(float(2 * precision * recall / (precision + recall + 1e-8)))
+        out.append(row)
+    return out
+
+
 def train_step_loss(nets, cfg, images, gt, epoch_idx: int = 0):
     """Forward of one training step (core/train.py:226-261, without autocast): returns
     (total_loss, encoder_loss, refiner_loss, merged_volume, refined_volume)."""

@@ -473,23 +473,39 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ x, c
   if (threadIdx.x == 0 && loss) atomicAdd(loss, acc / (float)n);
 }
 
-// ---- thresholded-occupancy counters for IoU (core/test.py:141-153): counts[b][th] = {intersection, union}
+// ---- thresholded-occupancy counters for IoU and F-score (core/test.py:141-163), every threshold from one pass:
+//      counts[b][th] = {intersection (= true positives), union, false positives, false negatives}
+constexpr int IOU_MAX_TH = 8;
 __global__ __launch_bounds__(256) void iou_counts_kernel(const float* __restrict__ logits, const float* __restrict__ gt, const float* __restrict__ ths,
                                                          int nth, int S, float* __restrict__ counts) {
   __shared__ float sc[4];
   const int b = blockIdx.x;
-  for (int k = 0; k < nth; ++k) {
-    const float th = ths[k];
-    float inter = 0.f, uni = 0.f;
-    for (int s = threadIdx.x; s < S; s += 256) {
-      const float xv = logits[(size_t)b * S + s];
-      const float pr = 1.f / (1.f + expf(-xv));
-      const float v = pr >= th ? 1.f : 0.f, gv = gt[(size_t)b * S + s];
-      inter += v * gv; uni += (v + gv >= 1.f) ? 1.f : 0.f;
+  float th[IOU_MAX_TH], acc[IOU_MAX_TH][4];
+#pragma unroll
+  for (int k = 0; k < IOU_MAX_TH; ++k) {
+    th[k] = k < nth ? ths[k] : 2.f;
+    acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.f;
+  }
+  for (int s = threadIdx.x; s < S; s += 256) {
+    const float xv = logits[(size_t)b * S + s], gv = gt[(size_t)b * S + s];
+    const float pr = 1.f / (1.f + expf(-xv));
+#pragma unroll
+    for (int k = 0; k < IOU_MAX_TH; ++k) {
+      const float v = pr >= th[k] ? 1.f : 0.f;
+      acc[k][0] += v * gv;
+      acc[k][1] += (v + gv >= 1.f) ? 1.f : 0.f;
+      acc[k][2] += v * (1.f - gv);
+      acc[k][3] += (1.f - v) * gv;
     }
-    inter = block_sum<4>(inter, sc);
-    uni = block_sum<4>(uni, sc);
-    if (threadIdx.x == 0) { counts[((size_t)b * nth + k) * 2] = inter; counts[((size_t)b * nth + k) * 2 + 1] = uni; }
+  }
+#pragma unroll
+  for (int k = 0; k < IOU_MAX_TH; ++k) {
+    if (k >= nth) break;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float r = block_sum<4>(acc[k][j], sc);
+      if (threadIdx.x == 0) counts[((size_t)b * nth + k) * 4 + j] = r;
+    }
   }
 }
 
@@ -675,7 +691,7 @@ extern "C" int sv_bce_logits(const float* x, const float* t, long long n, float*
   return check_launch("sv_bce_logits");
 }
 extern "C" int sv_iou_counts(const float* logits, const float* gt, const float* thresholds_dev, int nth, int B, int S, float* counts, void* stream) {
-  SV_REQUIRE(logits && gt && thresholds_dev && counts && nth > 0 && B > 0 && S > 0, "iou_counts: bad arguments");
+  SV_REQUIRE(logits && gt && thresholds_dev && counts && nth > 0 && nth <= IOU_MAX_TH && B > 0 && S > 0, "iou_counts: bad arguments (1..8 thresholds)");
   hipLaunchKernelGGL(iou_counts_kernel, dim3(B), dim3(256), 0, STREAM, logits, gt, thresholds_dev, nth, S, counts);
   return check_launch("sv_iou_counts");
 }

@@ -108,18 +108,46 @@ def train_step(nets, solvers, cfg, images, gt, epoch_idx: int = 0, reducer=None)
 
 
 @torch.no_grad()
-def evaluate(nets, cfg, images, gt, epoch_idx: int = 0):
-    """Returns (encoder_loss*10, refiner_loss*10, iou[B, n_thresholds]) - IoU per sample and threshold as in
-    core/test.py:141-153 (1.0 when prediction and ground truth are both empty)."""
-    total, el, rl, volume, _ = forward_losses(nets, cfg, images, gt, epoch_idx)
-    ths = torch.tensor(list(cfg.TEST.VOXEL_THRESH), dtype=torch.float32, device=volume.device)
+def voxel_metrics(volume, gt, thresholds):
+    """IoU and F-score of sigmoid(volume) >= th against gt for every sample and threshold, as core/test.py:141-163 defines
+    them (IoU 1.0 when prediction and ground truth are both empty; the 1e-8 epsilons of the F-score), from one kernel pass
+    over [B, 32^3] and no host synchronisation.  Returns (iou [B, n_th], fscore [B, n_th]) device tensors."""
+    hip.check_cuda(volume, gt)
     B = volume.shape[0]
-    counts = torch.empty(B, len(ths), 2, device=volume.device)
-    call("sv_iou_counts", ptr(volume.contiguous()), ptr(gt.contiguous()), ptr(ths), len(ths), B, 32768, ptr(counts))
-    inter, union = counts[..., 0], counts[..., 1]
-    iou = torch.where(union > 0, inter / union.clamp_min(1), torch.ones_like(inter))
-    return el * 10, rl * 10, iou
+    S_ = volume[0].numel()
+    ths = torch.tensor(list(thresholds), dtype=torch.float32, device=volume.device)
+    counts = torch.empty(B, len(ths), 4, device=volume.device)
+    call("sv_iou_counts", ptr(volume.contiguous()), ptr(gt.contiguous()), ptr(ths), len(ths), B, S_, ptr(counts))
+    tp, union, fp, fn = counts.unbind(-1)
+    iou = torch.where(union > 0, tp / union.clamp_min(1), torch.ones_like(tp))
+    precision = tp / (tp + fp + 1e-8)
+    recall = tp / (tp + fn + 1e-8)
+    return iou, 2 * precision * recall / (precision + recall + 1e-8)
 
+
+@torch.no_grad()
+def evaluate(nets, cfg, images, gt, epoch_idx: int = 0, with_fscore: bool = False):
+    """Returns (encoder_loss*10, refiner_loss*10, iou[B, n_thresholds]) (+ fscore[B, n_thresholds] with_fscore=True) for a
+    batch, per sample and threshold as in core/test.py:120-163."""
+    total, el, rl, volume, _ = forward_losses(nets, cfg, images, gt, epoch_idx)
+    iou, fs = voxel_metrics(volume, gt, cfg.TEST.VOXEL_THRESH)
+    return (el * 10, rl * 10, iou, fs) if with_fscore else (el * 10, rl * 10, iou)
+
+
+def aggregate_by_taxonomy(taxonomy_ids: Sequence, per_sample):
+    """core/test.py:187-203: per-taxonomy mean of per-sample metric rows and the sample-weighted overall mean.
+    `per_sample` is [N, n_thresholds] (tensor or nested list).  Returns ({taxonomy_id: (n_samples, mean_row)}, overall_row)."""
+    rows = torch.as_tensor(per_sample, dtype=torch.float64).cpu()
+    assert rows.shape[0] == len(taxonomy_ids)
+    out, order = {}, []
+    for i, t in enumerate(taxonomy_ids):
+        if t not in out:
+            out[t] = []
+            order.append(t)
+        out[t].append(rows[i])
+    table = {t: (len(out[t]), torch.stack(out[t]).mean(0)) for t in order}
+    overall = sum(n * m for n, m in table.values()) / len(taxonomy_ids)
+    return {t: (n, m.tolist()) for t, (n, m) in table.items()}, overall.tolist()
 
 _SCALER_STATE = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0}
 

@@ -68,3 +68,18 @@ def test_flat_solvers_refuse_cpu_parameters():
     from swinvox_amd.optim import FlatAdam
     with pytest.raises(RuntimeError, match="GPU"):
         FlatAdam(torch.nn.Linear(4, 4).parameters(), lr=1e-3)
+
+
+def test_taxonomy_aggregation_and_fscore_definition():
+    """core/test.py:187-203 (per-taxonomy mean, sample-weighted overall mean) and :155-163 (F-score with 1e-8 epsilons)."""
+    import oracle as O
+    table, overall = harness.aggregate_by_taxonomy(["a", "b", "a", "a"], [[1.0, 0.0], [0.5, 0.5], [0.0, 1.0], [0.5, 0.5]])
+    assert list(table) == ["a", "b"] and table["a"][0] == 3 and table["b"] == (1, [0.5, 0.5])
+    assert table["a"][1] == pytest.approx([0.5, 0.5]) and overall == pytest.approx([0.5, 0.5])
+    x = torch.full((1, 4, 4, 4), -9.0)
+    x[0, 0, 0, :2] = 9.0                      # two predicted voxels
+    g = torch.zeros(1, 4, 4, 4)
+    g[0, 0, 0, 1:4] = 1                       # three true voxels, one shared: TP 1, FP 1, FN 2
+    assert O.iou_at_thresholds(x, g)[0][0] == pytest.approx(1 / 4)
+    assert O.fscore_at_thresholds(x, g)[0][0] == pytest.approx(2 * 0.5 * (1 / 3) / (0.5 + 1 / 3), rel=1e-6)
+    assert O.fscore_at_thresholds(torch.full((1, 4, 4, 4), -9.0), torch.zeros(1, 4, 4, 4)) == [[0.0] * 4]

@@ -41,12 +41,20 @@ def test_train_steps_reduce_loss_and_eval_iou(dev, storage):
         assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
         for n in nets:
             n.eval()
-        el10, rl10, iou = harness.evaluate(nets, cfg, x, gt)
+        el10, rl10, iou, fsc = harness.evaluate(nets, cfg, x, gt, with_fscore=True)
         refined = nets[3](nets[2](*nets[1](nets[0](x))))
     finally:
         S.set_math("f32")
     ref = np.array(O.iou_at_thresholds(refined.detach().cpu(), gt.cpu()))
     assert iou.shape == (2, 4) and np.abs(iou.cpu().numpy() - ref).max() < 2e-3
+    reff = np.array(O.fscore_at_thresholds(refined.detach().cpu(), gt.cpu()))
+    assert fsc.shape == (2, 4) and np.abs(fsc.cpu().numpy() - reff).max() < 2e-3
+    # both empty -> IoU 1 (core/test.py:153); prediction empty, ground truth not -> IoU 0 and F-score 0
+    z = torch.full((2, 32, 32, 32), -9.0, device=dev)
+    g2 = torch.zeros(2, 32, 32, 32, device=dev)
+    g2[1, 0, 0, 0] = 1
+    i2, f2 = harness.voxel_metrics(z, g2, cfg.TEST.VOXEL_THRESH)
+    assert i2.tolist() == [[1.0] * 4, [0.0] * 4] and f2.tolist() == [[0.0] * 4, [0.0] * 4]
 
 
 def test_gating_without_merger_and_refiner(dev):

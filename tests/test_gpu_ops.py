@@ -464,13 +464,19 @@ def test_merge_bce_iou_dropout(dev):
     # IoU counters vs the reference definition
     import oracle as O
     ths = torch.tensor([0.2, 0.3, 0.4, 0.5])
-    cnt = ops.empty(B, 4, 2, device=dev)
+    cnt = ops.empty(B, 4, 4, device=dev)
     call("sv_iou_counts", ptr(keep(x.detach().to(dev))), ptr(keep(t.to(dev))), ptr(keep(ths.to(dev))), 4, B, S, ptr(cnt))
     ref = O.iou_at_thresholds(x.detach().view(B, 16, 16, 16), t.view(B, 16, 16, 16))
+    reff = O.fscore_at_thresholds(x.detach().view(B, 16, 16, 16), t.view(B, 16, 16, 16))
     c = cnt.cpu()
     for b in range(B):
         for k in range(4):
-            assert abs(float(c[b, k, 0] / c[b, k, 1]) - ref[b][k]) < 1e-3
+            tp, un, fp, fn = (float(v) for v in c[b, k])
+            assert abs(tp / un - ref[b][k]) < 1e-3 and abs(un - (tp + fp + fn)) < 0.5
+            pr, rc = tp / (tp + fp + 1e-8), tp / (tp + fn + 1e-8)
+            assert abs(2 * pr * rc / (pr + rc + 1e-8) - reff[b][k]) < 1e-3
+    with pytest.raises(RuntimeError, match="iou_counts"):
+        call("sv_iou_counts", ptr(x.detach().to(dev)), ptr(t.to(dev)), ptr(ths.to(dev)), 9, B, S, ptr(cnt))
     # dropout: mask statistics and fwd/bwd consistency
     n = 1 << 20
     ones = torch.ones(n, device=dev)
