@@ -234,6 +234,32 @@ int sv_adam_step(float* p, const float* g, float* m, float* v, long long n, doub
 int sv_sgd_step(float* p, const float* g, float* momentum_buf, long long n, double lr, double momentum, double weight_decay,
                 int first_step, float gscale, const double* slots16, float max_norm, void* stream);
 
+/* Input preparation on the device (the reference does it per sample on the CPU in DataLoader workers).
+ *  sv_binvox_decode: utils/binvox_rw.py:118-149 (read_as_3d_array) for B volumes of equal dims: `rle` holds the concatenated
+ *    (value, count) byte pairs that follow the "data" header line, volume b owning pairs [pair_offsets[b], pair_offsets[b+1]);
+ *    out[b] = float(np.repeat(values, counts) != 0).reshape(d0, d1, d2), transposed (0, 2, 1) when fix_coords (the loader's
+ *    default, utils/data_loaders.py:83-86).  decoded[b] = number of voxels the runs describe; the caller rejects a volume
+ *    whose count differs from d0*d1*d2 (the reference's reshape raises).
+ *  sv_augment_views: utils/data_transforms.py applied in the order of core/train.py:44-59 to I = B*V renderings stored as
+ *    8-bit [I][Hs][Ws][C] (C = 4 with alpha, or 3), without a bounding box: centre crop (crop_h, crop_w) when the image is
+ *    larger, cv2.resize INTER_LINEAR to (out_h, out_w), RandomBackground (alpha == 0 -> bg), ColorJitter, RandomNoise,
+ *    Normalize, RandomFlip, RandomPermuteRGB, ToTensor -> out [I][3][out_h][out_w] fp32.  One sv_aug_sample per SAMPLE (the
+ *    reference draws these once per __getitem__ and shares them between the V views), one flip byte per IMAGE.  The
+ *    validation pipeline (:60-65) is the same call with identity jitter / zero noise / no flips / identity permutation.
+ *    grey_sum_ws: I doubles of scratch (mean grey level per image for the contrast step).                               */
+typedef struct sv_aug_sample {
+  float bg[3];            /* background colour in [0, 1], channel order of the stored image                              */
+  float jitter_value[3];  /* blend factors: [0] brightness, [1] contrast, [2] saturation (1 = unchanged)                 */
+  int jitter_order[3];    /* the order the three adjustments are applied in (a permutation of 0, 1, 2)                    */
+  float noise[3];         /* RandomNoise offset per stored channel (noise_rgb reversed, data_transforms.py:386-390)       */
+  int perm[3];            /* output channel c = stored channel perm[c]                                                    */
+  float mean[3], std[3];  /* Normalize                                                                                    */
+} sv_aug_sample;
+int sv_binvox_decode(const unsigned char* rle, const long long* pair_offsets, int B, int d0, int d1, int d2, int fix_coords,
+                     float* out, int* decoded, void* stream);
+int sv_augment_views(const unsigned char* src, int I, int V, int Hs, int Ws, int C, int crop_h, int crop_w, int out_h, int out_w,
+                     const sv_aug_sample* params_dev, const unsigned char* flip_dev, double* grey_sum_ws, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,11 @@ class PackDesc(C.Structure):   # sv_pack_desc
                 ("rows_out", C.c_int), ("inner_out", C.c_int), ("block0", C.c_int), ("reserved", C.c_int)]
 
 
+class AugSample(C.Structure):   # sv_aug_sample
+    _fields_ = [("bg", C.c_float * 3), ("jitter_value", C.c_float * 3), ("jitter_order", C.c_int * 3), ("noise", C.c_float * 3),
+                ("perm", C.c_int * 3), ("mean", C.c_float * 3), ("std", C.c_float * 3)]
+
+
 # name -> (restype, argtypes); p = device/host pointer, i = int, l = long long, f = float, u = uint32, z = size_t
 _P, _I, _L, _F, _U, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint32, C.c_double
 # Entry points whose activation tensors are void* + `int act_dtype` (inserted by call() right before the stream argument)
@@ -106,6 +111,8 @@ _PROTOS = {
     "sv_mean_views": (_I, [_P, _P, _I, _I, _I]),
     "sv_bce_logits": (_I, [_P, _P, _L, _P, _P, _P]),
     "sv_iou_counts": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "sv_binvox_decode": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "sv_augment_views": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sv_grad_sumsq": (_I, [_P, _L, _F, _P]),
     "sv_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _L, _F, _P, _F]),
     "sv_sgd_step": (_I, [_P, _P, _P, _L, _D, _D, _D, _I, _F, _P, _F]),
