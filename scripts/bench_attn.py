@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import swinvox_amd as S
 from swinvox_amd import hip
 from swinvox_amd.hip import call, ptr
+if os.environ.get("SV_LIB"):
+    hip.LIB_PATH = os.environ["SV_LIB"]      # A/B builds of the library
 dev = torch.device("cuda", 0); hip.load(); S.set_math("bf16"); S.set_storage("bf16")
 def timeit(fn, iters=20):
     for _ in range(3): fn()
@@ -14,7 +16,7 @@ def timeit(fn, iters=20):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-I = 64
+I = int(os.environ.get("SV_ATTN_I", "64"))
 for H, heads in ((56, 3), (28, 6), (14, 12), (7, 24)):
     C = heads * 32
     rows = I * H * H

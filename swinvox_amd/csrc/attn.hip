@@ -627,13 +627,35 @@ __device__ __forceinline__ TokMap task_map(long long task, int nW, int nWx, int 
   return tm;
 }
 
+// (window chunk, head) of a workgroup in the 1-D grids of the workgroup-per-window kernels.  A head's slice of a token row is
+// 64 bytes - half a cache line - so the `heads` workgroups that walk the same windows must meet in one L2: consecutive
+// linear ids are spread round-robin over the 8 XCDs, ids l, l+8, l+16, ... therefore land on the SAME XCD back to back.
+// Those carry the heads of one chunk; the row is fetched from HBM once and the other heads hit in that XCD's L2.
+// Measured (I = 256): 8 % faster at 3 heads, 2-4 % at 6, and 4 % slower at 12+ heads (a token row is then >= 6 lines and
+// the heads of a chunk crowd one XCD), so wide stages keep the head-major order.
+__device__ __forceinline__ bool wg_chunk_head(int nchunks, int heads, int& chunk, int& head) {
+  const int l = blockIdx.x;
+  if (heads <= 6) {
+    const int xcd = l & 7, slot = l >> 3;
+    head = slot % heads;
+    chunk = (slot / heads) * 8 + xcd;
+  } else {
+    const int n8 = (nchunks + 7) & ~7;
+    head = l / n8;
+    chunk = l - head * n8;
+  }
+  return chunk < nchunks;
+}
+static inline unsigned wg_grid(int nchunks, int heads) { return 8u * (unsigned)heads * (unsigned)((nchunks + 7) / 8); }
+
 template <typename AT>
 __global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<AT> p) {
   __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * LDQ_H], Ks[64 * LDQ_H], Vt[HD * LDP_H], Ps[64 * LDP_H];
   __shared__ float bt[176];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int head = blockIdx.y;
+  int chunk, head;
+  if (!wg_chunk_head((p.ntasks + p.tasks_per_wave - 1) / p.tasks_per_wave, p.heads, chunk, head)) return;   // uniform over the workgroup
   const int nWx = p.W / 7, nW = (p.H / 7) * nWx;
   const int ld = 3 * p.C, colq = head * HD;
   for (int i = tid; i < 169; i += 256) bt[i] = p.table[i * p.heads + head];
@@ -641,7 +663,7 @@ __global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<
   __syncthreads();
   float bias[4][4];
   strip_bias(bias, bt, lane, wave);
-  const long long task0 = (long long)blockIdx.x * p.tasks_per_wave;
+  const long long task0 = (long long)chunk * p.tasks_per_wave;
   for (int tt = 0; tt < p.tasks_per_wave; ++tt) {
     const long long task = task0 + tt;
     if (task >= p.ntasks) break;                                         // uniform over the workgroup
@@ -712,7 +734,8 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
   __shared__ float bt[176], dbt[176];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int head = blockIdx.y;
+  int chunk, head;
+  if (!wg_chunk_head((p.ntasks + p.tasks_per_wave - 1) / p.tasks_per_wave, p.heads, chunk, head)) return;   // uniform over the workgroup
   const int nWx = p.W / 7, nW = (p.H / 7) * nWx;
   const int ld = 3 * p.C, colq = head * HD;
   for (int i = tid; i < 176; i += 256) { bt[i] = i < 169 ? p.table[i * p.heads + head] : 0.f; dbt[i] = 0.f; }
@@ -722,7 +745,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
   f32x4 dsum[4];                                   // sum over this workgroup's windows of dS at this lane's (query, key) slots
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) dsum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const long long task0 = (long long)blockIdx.x * p.tasks_per_wave;
+  const long long task0 = (long long)chunk * p.tasks_per_wave;
   for (int tt = 0; tt < p.tasks_per_wave; ++tt) {
     const long long task = task0 + tt;
     if (task >= p.ntasks) break;
@@ -817,7 +840,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
     }
   }
   __syncthreads();
-  float* dst = dt_ws ? dt_ws + (size_t)(blockIdx.x % ATTN_DT_SLOTS) * 169 * p.heads : p.dtable;
+  float* dst = dt_ws ? dt_ws + (size_t)(chunk % ATTN_DT_SLOTS) * 169 * p.heads : p.dtable;
   for (int i = tid; i < 169; i += 256) {
     const float v = dbt[i];
     if (v != 0.f) atomicAdd(dst + i * p.heads + head, v);
@@ -867,7 +890,7 @@ extern "C" int sv_window_attention_fwd(const void* qkv, const float* table, void
   hipStream_t s = (hipStream_t)stream;
   if (math == SV_MATH_BF16) {   // workgroup per window; a workgroup walks tpb windows of one head (>= ~2048 workgroups in the grid)
     int tpb = (int)((long long)ntasks * heads / 2048); if (tpb < 1) tpb = 1; if (tpb > 8) tpb = 8;
-    dim3 grid(cdiv(ntasks, tpb), heads);
+    dim3 grid(wg_grid(cdiv(ntasks, tpb), heads));
     if (act_dtype == SV_BF16) {
       WinArgsT<__bf16> a = win_args<__bf16>(qkv, table, out, nullptr, nullptr, nullptr, I, H, W, C, heads, shift);
       a.tasks_per_wave = tpb;
@@ -894,7 +917,7 @@ extern "C" int sv_window_attention_bwd(const void* qkv, const float* table, cons
   hipStream_t s = (hipStream_t)stream;
   if (math == SV_MATH_BF16) {   // workgroup per window, tpb windows of one head per workgroup
     int tpb = (int)((long long)ntasks * heads / 2048); if (tpb < 1) tpb = 1; if (tpb > 8) tpb = 8;
-    dim3 grid(cdiv(ntasks, tpb), heads);
+    dim3 grid(wg_grid(cdiv(ntasks, tpb), heads));
     if (act_dtype == SV_BF16) {
       WinArgsT<__bf16> a = win_args<__bf16>(qkv, table, nullptr, dout, dqkv, dtable, I, H, W, C, heads, shift);
       a.tasks_per_wave = tpb;
