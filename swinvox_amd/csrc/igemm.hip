@@ -1003,10 +1003,12 @@ extern "C" int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, 
   const int BNw = narrow ? WTileNarrow::BN : (wide ? WTileWide::BN : WTileDefault::BN);
   const int BKs = math == SV_MATH_BF16 ? 64 : 32;
   const int tiles = cdiv(g->Co, BMw) * cdiv(Kout, BNw);
-  // one full wave of workgroups (2 per CU x 256 CUs) and >= 8 K-steps per split: measured best on the bench shapes (fewer,
-  // longer splits halve the fp32 atomic traffic of the epilogue; more than one wave only adds tail)
-  const int target_blocks = 512, min_ksteps = 8;
-  long long splits = (target_blocks + tiles - 1) / tiles;
+  // at most ONE wave of workgroups (2 resident per CU x 256 CUs = 512 slots) and >= 8 K-steps per split.  Every workgroup
+  // does the same amount of work, so tiles * splits must not exceed the slots: rounding the split count UP (e.g. 36 tiles
+  // x 15 = 540) leaves a 28-workgroup second wave that costs as much as the first (measured: 173 -> ~90 us for 384x1536 over
+  // 50 176 rows).  Fewer, longer splits also halve the fp32 atomic traffic of the epilogue.
+  const int slots = 512, min_ksteps = 8;
+  long long splits = tiles <= slots ? slots / tiles : 1;
   const long long max_splits = (Mll + min_ksteps * BKs - 1) / (min_ksteps * BKs);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
