@@ -646,6 +646,14 @@ __device__ __forceinline__ bool wg_chunk_head(int nchunks, int heads, int& chunk
   }
   return chunk < nchunks;
 }
+// Windows per workgroup such that the whole grid is ONE resident wave (256 CUs x the kernel's workgroups per CU): every
+// workgroup does the same work, so a partially filled second wave costs as much as a full one.
+static inline int wg_tasks_per_block(int ntasks, int heads, int blocks_per_cu) {
+  int nchunks = 256 * blocks_per_cu / heads;
+  if (nchunks < 1) nchunks = 1;
+  if (nchunks > ntasks) nchunks = ntasks;
+  return (ntasks + nchunks - 1) / nchunks;
+}
 static inline unsigned wg_grid(int nchunks, int heads) { return 8u * (unsigned)heads * (unsigned)((nchunks + 7) / 8); }
 
 template <typename AT>
@@ -888,7 +896,8 @@ extern "C" int sv_window_attention_fwd(const void* qkv, const float* table, void
   SV_REQUIRE(out, "window_attention_fwd: null out");
   const int ntasks = I * (H / 7) * (W / 7);
   hipStream_t s = (hipStream_t)stream;
-  if (math == SV_MATH_BF16) {   // workgroup per window; a workgroup walks tpb windows of one head (>= ~2048 workgroups in the grid)
+  if (math == SV_MATH_BF16) {   // workgroup per window; a workgroup walks tpb windows of one head (>= ~2048 short workgroups:
+    // the forward task is brief, oversubscribing the CUs balances better than one exact wave - measured)
     int tpb = (int)((long long)ntasks * heads / 2048); if (tpb < 1) tpb = 1; if (tpb > 8) tpb = 8;
     dim3 grid(wg_grid(cdiv(ntasks, tpb), heads));
     if (act_dtype == SV_BF16) {
@@ -916,7 +925,7 @@ extern "C" int sv_window_attention_bwd(const void* qkv, const float* table, cons
   const int ntasks = I * (H / 7) * (W / 7);
   hipStream_t s = (hipStream_t)stream;
   if (math == SV_MATH_BF16) {   // workgroup per window, tpb windows of one head per workgroup
-    int tpb = (int)((long long)ntasks * heads / 2048); if (tpb < 1) tpb = 1; if (tpb > 8) tpb = 8;
+    const int tpb = wg_tasks_per_block(ntasks, heads, 3);
     dim3 grid(wg_grid(cdiv(ntasks, tpb), heads));
     if (act_dtype == SV_BF16) {
       WinArgsT<__bf16> a = win_args<__bf16>(qkv, table, nullptr, dout, dqkv, dtable, I, H, W, C, heads, shift);
