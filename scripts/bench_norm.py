@@ -6,6 +6,8 @@ import swinvox_amd as S
 from swinvox_amd import hip, ops
 from swinvox_amd.hip import call, ptr
 from swinvox_amd.ops import ACT_RELU, BatchNormState
+if os.environ.get("SV_LIB"):
+    hip.LIB_PATH = os.environ["SV_LIB"]
 dev = torch.device("cuda", 0); hip.load(); S.set_math("bf16"); S.set_storage("bf16")
 def timeit(fn, iters=20):
     for _ in range(3): fn()
@@ -15,7 +17,8 @@ def timeit(fn, iters=20):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-for M, C in ((802816, 64), (200704, 256), (200704, 64), (50176, 512), (50176, 128), (12544, 1024), (12544, 256)):
+SC = int(os.environ.get("SV_NORM_SCALE", "1"))   # 4 = the shapes of the default bench (256 images)
+for M, C in ((802816 * SC, 64), (200704 * SC, 256), (200704 * SC, 64), (50176 * SC, 512), (50176 * SC, 128), (12544 * SC, 1024), (12544 * SC, 256)):
     bn = torch.nn.BatchNorm1d(C).to(dev)
     x = torch.randn(M, C, device=dev).bfloat16(); dz = torch.randn(M, C, device=dev).bfloat16()
     z = torch.empty_like(x); dx = torch.empty_like(x); res = torch.randn(M, C, device=dev).bfloat16()
@@ -27,7 +30,7 @@ for M, C in ((802816, 64), (200704, 256), (200704, 64), (50176, 512), (50176, 12
     t2 = timeit(lambda: st.apply(x, C, z, C, ACT_RELU, 0.0, res, C))
     t3 = timeit(lambda: st.backward(dz, C, z, C, x, C, dx, C, dg, db, ACT_RELU, 0.0))
     print(f"BN M={M:7d} C={C:5d} ({mb:6.1f} MB/tensor)  apply {t1:7.1f} us {2*mb/t1*1e3:6.0f} GB/s | apply+res {t2:7.1f} us {3*mb/t2*1e3:6.0f} GB/s | bwd(reduce+apply) {t3:7.1f} us {7*mb/t3*1e3:6.0f} GB/s")
-for rows, C in ((200704, 96), (50176, 192), (12544, 384), (3136, 768)):
+for rows, C in ((200704 * SC, 96), (50176 * SC, 192), (12544 * SC, 384), (3136 * SC, 768)):
     x = torch.randn(rows, C, device=dev).bfloat16(); dy = torch.randn(rows, C, device=dev).bfloat16()
     g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     dx = torch.empty_like(x); dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
