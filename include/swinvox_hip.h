@@ -102,18 +102,23 @@ int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, float* dw, 
  * (= residual[pos*ldr + n] + value when residual != NULL); optional per-channel statistics as in sv_epilogue.stats
  * (ntiles16 == 1 only).  When ldc, col_off (and ldr) are multiples of 4 and the row has room, the columns
  * cout .. roundup4(cout)-1 are treated as PADDING of the row and written too (zero, + residual): 8/16-byte row stores.
- * Persistent kernel: one workgroup walks many 4x8x8 bricks, prefetching the next brick while it contracts the current one. */
+ * Persistent kernel: one workgroup walks many 4x8x8 bricks, prefetching the next brick while it contracts the current one.
+ * Planar channel storage (the dense per-layer buffers that replace the reference's torch.cat, merger.py:84): with
+ * x_plane_stride != 0 memory channel c of the input lives at x[(c / ldx) * x_plane_stride + pos*ldx + c % ldx]; with
+ * out_plane_stride != 0 column n goes to out[(n / ldc) * out_plane_stride + pos*ldc + n % ldc] (col_off 0, no residual).
+ * Strides in elements, multiples of 4; 0 = interleaved rows (sv_stencil3_wgrad: the same for its gathered operand x). */
 int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups, const void* w_bf16, int ntiles16,
                     const float* bias, void* out, int ldc, int col_off, int cout, const void* residual, int ldr,
-                    double* stats, int I, int D, int H, int W, int act_dtype, void* stream);
+                    double* stats, int I, int D, int H, int W, long long x_plane_stride, long long out_plane_stride, int act_dtype,
+                    void* stream);
 /* dw[co][ci][27] += sum_vox dy[vox][co] * x[vox + tap][c]; memory channel c maps to ci = (c / c_stride)*c_valid + c % c_stride;
  * optional dbias[co] += sum_vox dy[vox][co].  workspace: NULL (every workgroup adds into dw directly) or
  * sv_stencil3_wgrad_workspace_floats(cout, cin) floats, ZERO on entry: partial sums are spread over slot images and
  * folded into dw by a second small kernel (removes the ~1000-way atomic contention per weight) */
 size_t sv_stencil3_wgrad_workspace_floats(int cout, int cin);
 int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int groups, const void* dy, int lddy, int cout_load,
-                      float* dw, float* dbias, float* workspace, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W, int act_dtype,
-                      void* stream);
+                      float* dw, float* dbias, float* workspace, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W,
+                      long long x_plane_stride, int act_dtype, void* stream);
 /* dst[a][t][b] (b padded with zeros to pad_to) from the fp32 parameter src[a][b][t] (swap=0), or dst[b][t][a..pad_to] (swap=1);
  * dst elements are out_dtype (SV_F32 / SV_BF16) */
 int sv_pack_weight(const float* src, void* dst, int A, int B, int T, int swap, int pad_to, int out_dtype, void* stream);

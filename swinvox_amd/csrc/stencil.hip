@@ -29,6 +29,13 @@ __device__ __forceinline__ bf16x4 to_bf16x4(float4 v) {
 }
 __device__ __forceinline__ bf16x4 to_bf16x4(bf16x4 v) { return v; }
 
+// First brick of a persistent workgroup.  Workgroup ids are dealt round-robin over the 8 XCDs; giving XCD k the k-th
+// CONTIGUOUS eighth of every round of gridDim.x bricks keeps neighbouring bricks - which share 2.3x halo data - behind one L2.
+__device__ __forceinline__ int xcd_first_tile() {
+  const int n = gridDim.x, b = blockIdx.x;
+  return (n & 7) == 0 ? (b & 7) * (n >> 3) + (b >> 3) : b;
+}
+
 struct TileId { int img, z0, y0, x0; };
 __device__ __forceinline__ TileId tile_of(int t, int D, int H, int W) {
   const int tz = D / TZ, ty = H / TY, tx = W / TX;
@@ -42,7 +49,9 @@ template <int G, typename AT>
 struct HaloRegs {
   static constexpr int C = 16 * G, VPP = C / 4, N = (HPOS * VPP + 255) / 256;
   typename V4<AT>::type r[N];
-  __device__ __forceinline__ void load(const AT* __restrict__ x, int ldx, int cin_load, const TileId& t, int D, int H, int W, int tid) {
+  // plane == 0: position rows of ldx channels; plane != 0: the channels are stored as planes of ldx channels each
+  // (memory channel c at x[(c / ldx) * plane + pos * ldx + c % ldx]) - the dense per-layer buffers of the merger's concat
+  __device__ __forceinline__ void load(const AT* __restrict__ x, int ldx, long long plane, int cin_load, const TileId& t, int D, int H, int W, int tid) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const int i = tid + 256 * k;
@@ -51,8 +60,11 @@ struct HaloRegs {
         const int h = i / VPP, v = i - h * VPP;
         const int hx = h % HX; const int t2 = h / HX; const int hy = t2 % HY; const int hz = t2 / HY;
         const int z = t.z0 - 1 + hz, y = t.y0 - 1 + hy, xx = t.x0 - 1 + hx;
-        if (v * 4 < cin_load && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W)
-          q = V4<AT>::load(x + ((((size_t)t.img * D + z) * H + y) * W + xx) * (size_t)ldx + v * 4);
+        if (v * 4 < cin_load && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) {
+          const size_t pos = (((size_t)t.img * D + z) * H + y) * W + xx;
+          const int cv = v * 4, pl = plane ? cv / ldx : 0;
+          q = V4<AT>::load(x + (size_t)pl * plane + pos * (size_t)ldx + (cv - pl * ldx));
+        }
       }
       r[k] = q;
     }
@@ -69,6 +81,7 @@ struct HaloRegs {
 template <typename AT>
 struct StencilArgsT {                         // AT = storage element of the activations (x, out, residual)
   const AT* x; int ldx; int cin_load;         // input positions [I*D*H*W][ldx], cin_load (multiple of 4, <= 16*G) elements loaded per position
+  long long x_plane, out_plane;               // != 0: input channels / output columns stored as planes of ldx / ldc channels (see HaloRegs::load)
   const __bf16* w;                            // packed weights [NT*16][27][16*G]
   const float* bias; AT* out; int ldc; int col_off; int cout;   // columns written: n < cout (+ zero pads up to a multiple of 4, see header)
   const AT* residual; int ldr;                // optional: out = residual + val (same column window)
@@ -97,20 +110,20 @@ __global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgsT<AT
     *reinterpret_cast<bf16x8*>(Ws + n * KPAD + k) = v;
   }
   const int cs4 = (p.cout + 3) & ~3;
-  const bool vec_out = (p.ldc & 3) == 0 && (p.col_off & 3) == 0 && p.col_off + cs4 <= p.ldc && (!p.residual || ((p.ldr & 3) == 0 && cs4 <= p.ldr));
+  const bool vec_out = p.out_plane != 0 || (p.ldc & 3) == 0 && (p.col_off & 3) == 0 && p.col_off + cs4 <= p.ldc && (!p.residual || ((p.ldr & 3) == 0 && cs4 <= p.ldr));
   const int sn = tid & 15, srg = tid >> 4;           // statistics: column sn, voxel group srg (16 voxels)
   const float sbias = (p.bias && sn < p.cout) ? p.bias[sn] : 0.f;
   float st1 = 0.f, st2 = 0.f;
 
   HaloRegs<G, AT> hr;
-  int tile = blockIdx.x;
-  if (tile < p.ntiles) { hr.load(p.x, p.ldx, p.cin_load, tile_of(tile, p.D, p.H, p.W), p.D, p.H, p.W, tid); hr.store(Xs, tid); }
+  int tile = xcd_first_tile();
+  if (tile < p.ntiles) { hr.load(p.x, p.ldx, p.x_plane, p.cin_load, tile_of(tile, p.D, p.H, p.W), p.D, p.H, p.W, tid); hr.store(Xs, tid); }
   __syncthreads();
   const int yy = lr >> 3, xx = lr & 7;
   for (; tile < p.ntiles; tile += gridDim.x) {
     const TileId t = tile_of(tile, p.D, p.H, p.W);
     const int next = tile + gridDim.x;
-    if (next < p.ntiles) hr.load(p.x, p.ldx, p.cin_load, tile_of(next, p.D, p.H, p.W), p.D, p.H, p.W, tid);   // in flight during the MFMA loop
+    if (next < p.ntiles) hr.load(p.x, p.ldx, p.x_plane, p.cin_load, tile_of(next, p.D, p.H, p.W), p.D, p.H, p.W, tid);   // in flight during the MFMA loop
 
     // this wave: z-slice `wave`; M-tile mt = rows y = 2mt, 2mt+1; fragment row r = lane&15 -> (yy = r>>3, xx = r&7)
     f32x4 acc[4][NT];
@@ -164,7 +177,12 @@ __global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgsT<AT
             const float4 rv = ld4f(p.residual + pos * p.ldr + n0);
             v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
           }
-          st4f(p.out + pos * p.ldc + p.col_off + n0, make_float4(v[0], v[1], v[2], v[3]));
+          if (p.out_plane) {
+            const int pl = n0 / p.ldc;
+            st4f(p.out + (size_t)pl * p.out_plane + pos * p.ldc + (n0 - pl * p.ldc), make_float4(v[0], v[1], v[2], v[3]));
+          } else {
+            st4f(p.out + pos * p.ldc + p.col_off + n0, make_float4(v[0], v[1], v[2], v[3]));
+          }
         }
       } else {
         for (int n = 0; n < p.cout; ++n) {
@@ -199,6 +217,7 @@ __global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgsT<AT
 template <typename AT>
 struct StencilWArgsT {
   const AT* x; int ldx; int cin_load;        // gathered operand (conv input), memory channels = 16*G (zero-padded)
+  long long x_plane;                         // != 0: channel planes of ldx channels each (see HaloRegs::load)
   const AT* dy; int lddy; int cout_load;     // anchor operand (output gradient), <= 16 memory channels
   float* dw;                                 // native [cout][cin][27], accumulated with atomics (directly, or through `ws`)
   float* ws;                                 // optional [WG_SLOTS][cout*cin*27] zeroed slot images folded into dw by a second kernel
@@ -255,10 +274,10 @@ __global__ __launch_bounds__(256) void stencil3_wgrad_kernel(const StencilWArgsT
     for (int k = 0; k < 4; ++k) *reinterpret_cast<bf16x4*>(Ds + (tid + 256 * k) * 4) = to_bf16x4(dr[k]);   // [voxel][16] == linear i*4
   };
 
-  int tile = blockIdx.x;
+  int tile = xcd_first_tile();
   if (tile < p.ntiles) {
     const TileId t = tile_of(tile, p.D, p.H, p.W);
-    hr.load(p.x, p.ldx, p.cin_load, t, p.D, p.H, p.W, tid); load_dy(t);
+    hr.load(p.x, p.ldx, p.x_plane, p.cin_load, t, p.D, p.H, p.W, tid); load_dy(t);
     hr.store(Xs, tid); store_dy();
   }
   __syncthreads();
@@ -266,7 +285,7 @@ __global__ __launch_bounds__(256) void stencil3_wgrad_kernel(const StencilWArgsT
     const int next = tile + gridDim.x;
     if (next < p.ntiles) {
       const TileId t = tile_of(next, p.D, p.H, p.W);
-      hr.load(p.x, p.ldx, p.cin_load, t, p.D, p.H, p.W, tid); load_dy(t);     // in flight during the MFMA loop
+      hr.load(p.x, p.ldx, p.x_plane, p.cin_load, t, p.D, p.H, p.W, tid); load_dy(t);     // in flight during the MFMA loop
     }
     if (p.dbias) {
       const int c = tid & 15, vg = tid >> 4;
@@ -346,12 +365,17 @@ static int stencil_check(int I, int D, int H, int W) {
 
 extern "C" int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups, const void* w_bf16, int ntiles16,
                                const float* bias, void* out, int ldc, int col_off, int cout, const void* residual, int ldr,
-                               double* stats, int I, int D, int H, int W, int act_dtype, void* stream) {
+                               double* stats, int I, int D, int H, int W, long long x_plane_stride, long long out_plane_stride,
+                               int act_dtype, void* stream) {
   SV_REQUIRE(x && w_bf16 && out, "stencil3_fwd: null argument");
+  SV_REQUIRE(x_plane_stride >= 0 && out_plane_stride >= 0 && x_plane_stride % 4 == 0 && out_plane_stride % 4 == 0, "stencil3_fwd: bad plane strides");
+  SV_REQUIRE(!out_plane_stride || (col_off == 0 && !residual && ldc % 4 == 0 && cout % ldc == 0),
+             "stencil3_fwd: planar output needs col_off == 0, no residual and whole planes of ldc (multiple of 4) columns");
   SV_REQUIRE_ACT(act_dtype);
   if (int rc = stencil_check(I, D, H, W)) return rc;
-  SV_REQUIRE(cin_load % 4 == 0 && cin_load <= 16 * groups && ldx % 4 == 0 && ldx >= cin_load, "stencil3_fwd: bad input channels (cin_load=%d ldx=%d groups=%d)", cin_load, ldx, groups);
-  SV_REQUIRE(cout > 0 && cout <= 16 * ntiles16 && ldc >= col_off + cout, "stencil3_fwd: bad output window");
+  SV_REQUIRE(cin_load % 4 == 0 && cin_load <= 16 * groups && ldx % 4 == 0 && (x_plane_stride ? cin_load % ldx == 0 : ldx >= cin_load),
+             "stencil3_fwd: bad input channels (cin_load=%d ldx=%d groups=%d)", cin_load, ldx, groups);
+  SV_REQUIRE(cout > 0 && cout <= 16 * ntiles16 && (out_plane_stride || ldc >= col_off + cout), "stencil3_fwd: bad output window");
   SV_REQUIRE(!stats || ntiles16 == 1, "stencil3_fwd: statistics need a single 16-column tile");
   const uintptr_t amask = act_dtype == SV_BF16 ? 7 : 15;
   SV_REQUIRE(((uintptr_t)x & amask) == 0 && ((uintptr_t)w_bf16 & 15) == 0, "stencil3_fwd: operands must be aligned to 4 elements");
@@ -367,7 +391,7 @@ extern "C" int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups,
   const int resident = 256 * (groups == 1 && ntiles16 == 1 ? 3 : 1);
   const int blocks = ntiles < resident ? ntiles : resident;
   SV_DISPATCH_ACT(act_dtype,
-    StencilArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, (const __bf16*)w_bf16, bias, static_cast<AT*>(out), ldc, col_off, cout,
+    StencilArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, x_plane_stride, out_plane_stride, (const __bf16*)w_bf16, bias, static_cast<AT*>(out), ldc, col_off, cout,
                        static_cast<const AT*>(residual), ldr, stats, I, D, H, W, ntiles};
     if (groups == 1 && ntiles16 == 1) hipLaunchKernelGGL((stencil3_fwd_kernel<1, 1, AT>), dim3(blocks), dim3(256), 0, s, a);
     else if (groups == 3) hipLaunchKernelGGL((stencil3_fwd_kernel<3, 1, AT>), dim3(blocks), dim3(256), 0, s, a);
@@ -379,8 +403,9 @@ extern "C" size_t sv_stencil3_wgrad_workspace_floats(int cout, int cin) { return
 
 extern "C" int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int groups, const void* dy, int lddy, int cout_load,
                                  float* dw, float* dbias, float* workspace, int cout, int cin, int c_stride, int c_valid, int I, int D, int H,
-                                 int W, int act_dtype, void* stream) {
+                                 int W, long long x_plane_stride, int act_dtype, void* stream) {
   SV_REQUIRE(x && dy && dw, "stencil3_wgrad: null argument");
+  SV_REQUIRE(x_plane_stride >= 0 && x_plane_stride % 4 == 0 && (!x_plane_stride || cin_load % ldx == 0), "stencil3_wgrad: bad plane stride");
   SV_REQUIRE_ACT(act_dtype);
   if (int rc = stencil_check(I, D, H, W)) return rc;
   SV_REQUIRE(cin_load % 4 == 0 && cin_load <= 16 * groups && ldx % 4 == 0 && cout_load % 4 == 0 && cout_load <= 16 && lddy % 4 == 0,
@@ -393,7 +418,7 @@ extern "C" int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int group
   const int blocks = ntiles < resident ? ntiles : resident;
   hipStream_t s = (hipStream_t)stream;
   SV_DISPATCH_ACT(act_dtype,
-    StencilWArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, static_cast<const AT*>(dy), lddy, cout_load, dw, workspace, dbias, cout, cin, c_stride, c_valid,
+    StencilWArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, x_plane_stride, static_cast<const AT*>(dy), lddy, cout_load, dw, workspace, dbias, cout, cin, c_stride, c_valid,
                         I, D, H, W, ntiles};
     if (groups == 1) hipLaunchKernelGGL((stencil3_wgrad_kernel<1, AT>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((stencil3_wgrad_kernel<3, AT>), dim3(blocks), dim3(256), 0, s, a););

@@ -72,10 +72,10 @@ class Merger(HipModule):
         return wp.to(torch.bfloat16).contiguous()
 
     def _conv_fwd(self, li, x, ldi, y, ldc, stats, w5p=None):
-        conv, I = self._layer(li)[0], x.shape[0] // VOX
-        if ops.get_math() == "bf16":
+        conv, I = self._layer(li)[0], y.shape[0] // VOX
+        if ops.get_math() == "bf16":   # layer 5 reads the four dense 12-wide planes of the concat
             call("sv_stencil3_fwd", ptr(x), ldi, 48 if li == 4 else 12, 3 if li == 4 else 1, ptr(self._stencil_pack(li, False)), 1,
-                 ptr(conv.bias), ptr(y), ldc, 0, conv.out_channels, None, 0, ptr(stats), I, 32, 32, 32)
+                 ptr(conv.bias), ptr(y), ldc, 0, conv.out_channels, None, 0, ptr(stats), I, 32, 32, 32, I * VOX * 12 if li == 4 else 0, 0)
         else:
             sp = self._spec(li)
             sp.forward(x, I, G, sp.pack_fwd(w5p if li == 4 else conv.weight), y, ldi=ldi, ldc=ldc, bias=conv.bias, stats=stats)
@@ -84,7 +84,8 @@ class Merger(HipModule):
         conv, I = self._layer(li)[0], dy.shape[0] // VOX
         if ops.get_math() == "bf16":
             call("sv_stencil3_fwd", ptr(dy), lddy, lddy if lddy <= 12 else 12, 1, ptr(self._stencil_pack(li, True)), 3 if li == 4 else 1,
-                 None, ptr(dx), lddx, 0, 48 if li == 4 else 9, ptr(dx) if accumulate else None, lddx, None, I, 32, 32, 32)
+                 None, ptr(dx), lddx, 0, 48 if li == 4 else 9, ptr(dx) if accumulate else None, lddx, None, I, 32, 32, 32,
+                 0, I * VOX * 12 if li == 4 else 0)
         else:
             sp = self._spec(li)
             epi = dict(residual=dx, ldr=lddx) if accumulate else {}
@@ -95,7 +96,8 @@ class Merger(HipModule):
         if ops.get_math() == "bf16":
             ws = ops.zeros_f64(8 * conv.out_channels * conv.in_channels * 27, dy.device)   # 16 slot images of floats, zero on entry
             call("sv_stencil3_wgrad", ptr(x), ldx, 48 if li == 4 else 12, 3 if li == 4 else 1, ptr(dy), lddy, lddy if lddy <= 12 else 12,
-                 ptr(grads[conv.weight]), ptr(grads[conv.bias]), ptr(ws), conv.out_channels, conv.in_channels, 12 if li == 4 else 16, 9, I, 32, 32, 32)
+                 ptr(grads[conv.weight]), ptr(grads[conv.bias]), ptr(ws), conv.out_channels, conv.in_channels, 12 if li == 4 else 16, 9, I, 32, 32, 32,
+                 I * VOX * 12 if li == 4 else 0)
         elif li == 4:
             dw5p = fzeros(9, 48, 27, like=dy)
             self._s5.wgrad(dy, x, I, G, dw5p, lddy=lddy, ldx=ldx, async_ok=False)   # dw5p is read back right below
@@ -115,8 +117,13 @@ class Merger(HipModule):
         M, tr, sl = B * V * VOX, self.training, self._slope
         x12 = ops.to_store(as_channels_last12(raw))
         vol = ops.to_store(vol)
-        cat = zeros(M, 48, like=vol)
-        w5p = self._w5_padded() if ops.get_math() != "bf16" else None
+        # the reference's torch.cat of the four 9-channel maps (merger.py:84) is never materialised: layers 1-4 write their
+        # activations where layer 5 reads them.  Stencil back-end: four DENSE planes [4][M][12] (every per-layer pass streams
+        # whole cache lines); generic fp32 engine: 12-column windows of 48-wide rows (one 48-channel input).
+        planar = ops.get_math() == "bf16"
+        cat = zeros(4, M, 12, like=vol) if planar else zeros(M, 48, like=vol)
+        ldz = 12 if planar else 48
+        w5p = self._w5_padded() if not planar else None
         ctx14, xin, ldi = [], x12, 12
         for k in range(4):
             bn = self._layer(k)[1]
@@ -124,13 +131,13 @@ class Merger(HipModule):
             st = BatchNormState(bn, M, tr)
             self._conv_fwd(k, xin, ldi, y, 12, st.sums)
             st.finalize()
-            z = cat[:, 12 * k:]
-            st.apply(y, 12, z, 48, ACT_LRELU, sl)
+            z = cat[k] if planar else cat[:, 12 * k:]
+            st.apply(y, 12, z, ldz, ACT_LRELU, sl)
             ctx14.append((xin, ldi, y, z, st))
-            xin, ldi = z, 48
+            xin, ldi = z, ldz
         y5 = empty(M, 12, like=vol)
         st5 = BatchNormState(self.layer5[1], M, tr)
-        self._conv_fwd(4, cat, 48, y5, 12, st5.sums, w5p)
+        self._conv_fwd(4, cat, ldz, y5, 12, st5.sums, w5p)
         st5.finalize()
         z5 = zeros(M, 12, like=vol)
         st5.apply(y5, 12, z5, 12, ACT_LRELU, sl)
@@ -165,21 +172,24 @@ class Merger(HipModule):
         dy5 = zeros(M, 12, like=vol)
         st5.backward(dz5, 12, z5, 12, y5, 12, dy5, 12, grads[bn5.weight], grads[bn5.bias], ACT_LRELU, sl)
         self._bias_grad(dy5, M, 9, 12, grads[conv5.bias])
-        self._conv_wgrad(4, dy5, 12, cat, 48, grads)
-        dcat = zeros(M, 48, like=vol)   # data-gradient wrt the 48-wide concat buffer (pad columns receive zero weights)
-        self._conv_dgrad(4, dy5, 12, dcat, 48, False, w5p)
+        planar = cat.dim() == 3
+        ldz = 12 if planar else 48
+        self._conv_wgrad(4, dy5, 12, cat, ldz, grads)
+        # data-gradient wrt the concat buffer, same storage scheme as `cat` (pad columns receive zero weights)
+        dcat = zeros(4, M, 12, like=vol) if planar else zeros(M, 48, like=vol)
+        self._conv_dgrad(4, dy5, 12, dcat, ldz, False, w5p)
         # ---- layers 4..1: z_k feeds layer k+1 and the concat -> gradients add up in dcat[:, 12k:12k+9]
         dx = None
         for k in (3, 2, 1, 0):
             conv, bn = self._layer(k)[0], self._layer(k)[1]
             xin, ldi, y, z, st = ctx14[k]
-            dzk = dcat[:, 12 * k:]
+            dzk = dcat[k] if planar else dcat[:, 12 * k:]
             dy = zeros(M, 12, like=vol)
-            st.backward(dzk, 48, z, 48, y, 12, dy, 12, grads[bn.weight], grads[bn.bias], ACT_LRELU, sl)
+            st.backward(dzk, ldz, z, ldz, y, 12, dy, 12, grads[bn.weight], grads[bn.bias], ACT_LRELU, sl)
             self._bias_grad(dy, M, 9, 12, grads[conv.bias])
             self._conv_wgrad(k, dy, 12, xin, ldi, grads)
             if k > 0:   # accumulate into the previous layer's slot of dcat
-                self._conv_dgrad(k, dy, 12, dcat[:, 12 * (k - 1):], 48, True)
+                self._conv_dgrad(k, dy, 12, dcat[k - 1] if planar else dcat[:, 12 * (k - 1):], ldz, True)
             else:
                 dx = zeros(M, 12, like=vol)
                 self._conv_dgrad(k, dy, 12, dx, 12, False)

@@ -367,11 +367,11 @@ def test_merger_stencils(dev, li):
         y = ops.zeros(M, 12, device=dev)
         stats = torch.zeros(ops.BN_SLOTS, 18, dtype=torch.float64, device=dev)
         call("sv_stencil3_fwd", ptr(xd), cin_mem, cin_mem, groups, ptr(D(wp, dev)), 1, ptr(D(bias, dev)), ptr(y), 12, 0, 9, None, 0, ptr(stats),
-             I, Dg, Dg, Dg)
+             I, Dg, Dg, Dg, 0, 0)
         cin = 36 if li == 4 else 9
         dw, db = ops.fzeros(9, cin, 27, device=dev), ops.fzeros(9, device=dev)
         ws = ops.fzeros(int(hip.load().sv_stencil3_wgrad_workspace_floats(9, cin)), device=dev)
-        call("sv_stencil3_wgrad", ptr(xd), cin_mem, cin_mem, groups, ptr(A(dy)), 12, 12, ptr(dw), ptr(db), ptr(ws), 9, cin, 12 if li == 4 else 16, 9, I, Dg, Dg, Dg)
+        call("sv_stencil3_wgrad", ptr(xd), cin_mem, cin_mem, groups, ptr(A(dy)), 12, 12, ptr(dw), ptr(db), ptr(ws), 9, cin, 12 if li == 4 else 16, 9, I, Dg, Dg, Dg, 0)
         return dict(y=y, stats=stats.sum(0).float(), dw=dw, db=db)
 
     both(run, dev)

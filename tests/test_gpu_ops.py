@@ -519,7 +519,7 @@ def test_stencil3_fwd_dgrad_wgrad(dev, cin, cout, groups):
     xd, wfd, bd = xm.to(dev), wf.to(dev).bfloat16().contiguous(), b.to(dev)
     out = ops.zeros(M, 12, device=dev)
     stats = torch.zeros(ops.BN_SLOTS, 2 * cout, dtype=torch.float64, device=dev)
-    call("sv_stencil3_fwd", ptr(xd), ld, ld, groups, ptr(wfd), 1, ptr(bd), ptr(out), 12, 0, cout, None, 0, ptr(stats), n, D, D, D)
+    call("sv_stencil3_fwd", ptr(xd), ld, ld, groups, ptr(wfd), 1, ptr(bd), ptr(out), 12, 0, cout, None, 0, ptr(stats), n, D, D, D, 0, 0)
     ref = cl(y.detach()).reshape(M, cout)
     assert rel(out[:, :cout], ref) < 2e-5
     st = stats.sum(0)
@@ -531,9 +531,23 @@ def test_stencil3_fwd_dgrad_wgrad(dev, cin, cout, groups):
     dyd, wdd = dym.to(dev), wd.to(dev).bfloat16().contiguous()
     base = torch.randn(M, ld, generator=g)
     dx = base.clone().to(dev)
-    call("sv_stencil3_fwd", ptr(dyd), 12, 12, 1, ptr(wdd), nt, None, ptr(dx), ld, 0, ld if groups == 3 else 9, ptr(dx), ld, None, n, D, D, D)
+    call("sv_stencil3_fwd", ptr(dyd), 12, 12, 1, ptr(wdd), nt, None, ptr(dx), ld, 0, ld if groups == 3 else 9, ptr(dx), ld, None, n, D, D, D, 0, 0)
     assert rel((dx.cpu() - base)[:, cols], cl(x.grad).reshape(M, cin)) < 2e-5
     # weight gradient (bf16 operands, fp32 atomics)
     dw = ops.zeros(cout, cin, 3, 3, 3, device=dev)
-    call("sv_stencil3_wgrad", ptr(xd), ld, ld, groups, ptr(dyd), 12, 12, ptr(dw), None, None, cout, cin, 16 if groups == 1 else 12, 9, n, D, D, D)
+    call("sv_stencil3_wgrad", ptr(xd), ld, ld, groups, ptr(dyd), 12, 12, ptr(dw), None, None, cout, cin, 16 if groups == 1 else 12, 9, n, D, D, D, 0)
     assert rel(dw, w.grad) < 2e-4
+    if groups == 3:
+        # planar channel storage (four dense 12-wide planes instead of 48-wide rows): same numbers from / into the planes
+        xp = xm.view(M, 4, 12).permute(1, 0, 2).contiguous().to(dev)                      # [4][M][12]
+        out2 = ops.zeros(M, 12, device=dev)
+        call("sv_stencil3_fwd", ptr(xp), 12, 48, 3, ptr(wfd), 1, ptr(bd), ptr(out2), 12, 0, cout, None, 0, None, n, D, D, D, M * 12, 0)
+        assert torch.equal(out2, out)
+        dxp = ops.zeros(4, M, 12, device=dev)
+        call("sv_stencil3_fwd", ptr(dyd), 12, 12, 1, ptr(wdd), 3, None, ptr(dxp), 12, 0, 48, None, 0, None, n, D, D, D, 0, M * 12)
+        assert rel(dxp.permute(1, 0, 2).reshape(M, 48).cpu()[:, cols], cl(x.grad).reshape(M, cin)) < 2e-5
+        dw2 = ops.zeros(cout, cin, 3, 3, 3, device=dev)
+        call("sv_stencil3_wgrad", ptr(xp), 12, 48, 3, ptr(dyd), 12, 12, ptr(dw2), None, None, cout, cin, 12, 9, n, D, D, D, M * 12)
+        assert rel(dw2, w.grad) < 2e-4
+        with pytest.raises(RuntimeError, match="planar output"):
+            call("sv_stencil3_fwd", ptr(dyd), 12, 12, 1, ptr(wdd), 3, None, ptr(dxp), 12, 4, 48, None, 0, None, n, D, D, D, 0, M * 12)
