@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..ops import ACT_NONE, ACT_RELU, ConvSpec, call, empty, ptr, zeros
+from ..ops import ACT_NONE, ACT_RELU, BatchNormState, ConvSpec, call, empty, ptr, zeros
 from ._base import ConvBnAct, HipModule, conv_spec_of
 from .cross_view_attention import CrossViewAttention
 from .swin_transformer import SwinTransformer, swin_backward, swin_forward
@@ -92,7 +92,10 @@ class Encoder(HipModule):
 
         self.fusion_layer, self.layer1, self.layer2, self.layer3 = cbr(512), cbr(256), cbr(256), cbr(256)
         # kernel-chain helpers (no parameters of their own)
-        self._stem = ConvBnAct(self.resnet[0], self.resnet[1], conv_spec_of(self.resnet[0]), ACT_RELU)
+        # ResNet stem (7x7 / stride 2 / pad 3 on 3 channels) as a 4x4 / stride 1 convolution on the space-to-depth image
+        # [112][112][(sy, sx, c) = 16]: input row 2*oy - 3 + ky = 2*(oy - 2 + ty) + sy with ky = 2*ty + sy - 1, i.e. pads (2, 1) and
+        # an explicit 112 x 112 output grid.  Same products, but every tap is a 32-byte channel vector instead of 3 scalars.
+        self._stem_spec = ConvSpec.conv2d(16, 64, 4, 1, 2, og_fixed=(1, 112, 112))
         self._s_rr = ConvSpec.linear(1024, 256)
         self._post = [ConvBnAct(m[0], m[1], conv_spec_of(m[0]), ACT_RELU) for m in (self.fusion_layer, self.layer1, self.layer2, self.layer3)]
         if n.USE_SWIN_T_MULTI_STAGE:
@@ -106,6 +109,38 @@ class Encoder(HipModule):
         assert rendering_images.dim() == 5 and rendering_images.shape[2] == 3, "expected [B, V, 3, H, W]"
         assert tuple(rendering_images.shape[-2:]) == (224, 224), "swinvox_amd: images must be 224x224 (reference cfg.CONST.IMG_H/W)"
         return self._run(rendering_images)
+
+    # ---- ResNet stem on the space-to-depth image --------------------------------------------------------
+    def _stem_pack(self):
+        """[64,3,7,7] -> forward pack [cout][tap (ty,tx)][16 = (sy,sx,c)] of the 4x4 formulation (ky = 2ty+sy-1, kx = 2tx+sx-1)."""
+        w = self.resnet[0].weight.detach()
+        w8 = w.new_zeros(64, 4, 8, 8)
+        w8[:, :3, 1:, 1:] = w
+        wp = w8.view(64, 4, 4, 2, 4, 2).permute(0, 2, 4, 3, 5, 1).reshape(64, 16, 16)      # [co,c,ty,sy,tx,sx] -> [co,ty,tx,sy,sx,c]
+        return wp.to(ops._STATE["store"]).contiguous()
+
+    def _stem_fwd(self, images, I, tr):
+        x16 = zeros(I, 112, 112, 2, 2, 4, like=images)                   # channel 3 of every (sy, sx) group stays zero
+        x16[..., :3].copy_(images.view(I, 3, 112, 2, 112, 2).permute(0, 2, 4, 3, 5, 1))
+        x16 = x16.view(I * 112 * 112, 16)
+        sp, bn, M = self._stem_spec, self.resnet[1], I * 112 * 112
+        y = empty(M, 64, like=x16)
+        st = BatchNormState(bn, M, tr)
+        sp.forward(x16, I, (1, 112, 112), self._stem_pack(), y, stats=st.sums)
+        st.finalize()
+        z = empty(M, 64, like=x16)
+        st.apply(y, 64, z, 64, ACT_RELU, 0.0)
+        return z, (1, 112, 112), (x16, y, st, M, I)
+
+    def _stem_bwd(self, ctx, dz, grads):
+        x16, y, st, M, I = ctx
+        conv, bn = self.resnet[0], self.resnet[1]
+        dy = empty(M, 64, like=dz)
+        st.backward(dz, 64, None, 64, y, 64, dy, 64, grads[bn.weight], grads[bn.bias], ACT_RELU, 0.0)
+        dw16 = ops.fzeros(64, 16, 4, 4, like=dy)                         # native layout of the 4x4 formulation: [co][(sy,sx,c)][ty][tx]
+        self._stem_spec.wgrad(dy, x16, I, (1, 112, 112), dw16, async_ok=False)   # read back right below
+        g8 = dw16.view(64, 2, 2, 4, 4, 4).permute(0, 3, 4, 1, 5, 2).reshape(64, 4, 8, 8)   # -> [co, c, 2ty+sy, 2tx+sx]
+        grads[conv.weight].add_(g8[:, :3, 1:, 1:])
 
     # ------------------------------------------------------------------------------------------------
     def _fwd(self, images, save):
@@ -125,7 +160,7 @@ class Encoder(HipModule):
             neck = self._swin_branch_fwd(img, cat, I, tr, sto, seeds, multi)
         swin_tape = neck.pop()
         # ---- ResNet trunk
-        x, g, c_stem = self._stem.forward(img, I, (1, 224, 224), tr)
+        x, g, c_stem = self._stem_fwd(images, I, tr)
         mp = empty(I * 56 * 56, 64, like=x)
         mp_idx = torch.empty(I * 56 * 56 * 64, dtype=torch.uint8, device=x.device)
         call("sv_maxpool2d_fwd", ptr(x), ptr(mp), ptr(mp_idx), I, 112, 112, 64)
@@ -239,6 +274,6 @@ class Encoder(HipModule):
             d = blk.bwd(c, d, grads)
         dmp = empty(I * 112 * 112, 64, like=dout)                            # the gather-form max-pool backward writes every element
         call("sv_maxpool2d_bwd", ptr(d), ptr(mp_idx), ptr(dmp), I, 112, 112, 64)
-        self._stem.backward(c_stem, dmp, 64, grads, need_dx=False)
+        self._stem_bwd(c_stem, dmp, grads)
         main.wait_stream(side)                                             # join: every parameter gradient is complete
         return (None,)

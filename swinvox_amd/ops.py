@@ -119,6 +119,7 @@ class ConvSpec:
     transposed: bool = False
     cin_mem: Optional[int] = None    # channels the input activation holds in memory (zero-padded), default cin
     cout_mem: Optional[int] = None   # channels the output-gradient holds in memory, default cout
+    og_fixed: Optional[Tuple[int, int, int]] = None   # output grid when it is not the symmetric-padding formula (asymmetric pads)
 
     def __post_init__(self):
         self.cin_mem = self.cin_mem or self.cin
@@ -139,6 +140,8 @@ class ConvSpec:
         return ConvSpec(cin, cout)
 
     def out_grid(self, g):
+        if self.og_fixed is not None:
+            return tuple(self.og_fixed)
         if self.transposed:
             return tuple((g[i] - 1) * self.s[i] - 2 * self.p[i] + self.k[i] for i in range(3))
         return tuple((g[i] + 2 * self.p[i] - self.k[i]) // self.s[i] + 1 for i in range(3))
