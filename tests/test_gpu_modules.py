@@ -39,7 +39,7 @@ def grad_report(items, factor=4.0, floor_l1=5e-3, floor_max=5e-2):
 
     Two fp32 forwards (HIP vs CPU) differ by rounding, so a max-pool arg-max or a (Leaky)ReLU mask occasionally flips
     at a near-tie; one flip re-routes ONE gradient element and moves a whole conv-weight gradient by O(1%) of its max
-    (measured: scripts/debug_tail_grads2.py - the contraction kernels themselves are exact to 3e-7 on the same
+    (measured: scripts/grad_mask_flip_study.py - the contraction kernels themselves are exact to 3e-7 on the same
     tensors).  Train-mode BatchNorm over a handful of images additionally makes some ResNet gradients ill-conditioned:
     the CPU fp32 oracle itself is up to 17% off the fp64 truth there.  Hence: the L1-relative error must be within
     `factor` x the CPU-fp32 oracle's own L1 error + floor_l1, and the max-norm error within factor x e32 + floor_max;
