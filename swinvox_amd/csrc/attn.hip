@@ -606,6 +606,9 @@ __device__ __forceinline__ void bias_mask_softmax_strip(f32x4 (&s)[4], const flo
   }
 }
 
+__device__ __forceinline__ float4 to_f4(float4 v) { return v; }
+__device__ __forceinline__ float4 to_f4(bf16x4 b) { return make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]); }
+
 // cooperative (256 threads) load of one [49(64) x 32] head slice into a bf16 LDS tile [64][LDQ_H]; rows >= 49 zeroed
 template <typename AT>
 __device__ __forceinline__ void load_tile_wg(__bf16* dst, const AT* src, int ld, int col, const TokMap& tm, int tid, float mul) {
@@ -754,16 +757,41 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) dsum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const long long task0 = (long long)chunk * p.tasks_per_wave;
+  // the next window's q / k / v / dO vectors travel in registers while this window is contracted: a window is
+  // load -> barrier -> MFMA -> softmax -> barrier -> MFMA -> store, and three workgroups per CU do not hide a global round trip
+  typedef typename V4<AT>::type RV;
+  RV rq[2], rk[2], rv[2], rd[2];
+  auto fetch = [&](long long task) {
+    const TokMap tn = task_map(task, nW, nWx, p.H, p.W, p.shift);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int r = (tid >> 3) + 32 * it, ch = (tid & 7) * 4;
+      rq[it] = V4<AT>::zero(); rk[it] = rq[it]; rv[it] = rq[it]; rd[it] = rq[it];
+      if (r < WT) {
+        const size_t row = tn.row(r);
+        const AT* src = p.qkv + row * ld + colq + ch;
+        rq[it] = V4<AT>::load(src); rk[it] = V4<AT>::load(src + p.C); rv[it] = V4<AT>::load(src + 2 * p.C);
+        rd[it] = V4<AT>::load(p.dout + row * p.C + colq + ch);
+      }
+    }
+  };
+  auto put = [&](__bf16* dst, const RV& v, int it, float mul) {
+    const int r = (tid >> 3) + 32 * it, ch = (tid & 7) * 4;
+    const float4 f = to_f4(v);
+    bf16x4 b;
+    b[0] = (__bf16)(f.x * mul); b[1] = (__bf16)(f.y * mul); b[2] = (__bf16)(f.z * mul); b[3] = (__bf16)(f.w * mul);
+    *reinterpret_cast<bf16x4*>(dst + r * LDQ_H + ch) = b;
+  };
+  if (task0 < p.ntasks) fetch(task0);
   for (int tt = 0; tt < p.tasks_per_wave; ++tt) {
     const long long task = task0 + tt;
     if (task >= p.ntasks) break;
     const TokMap tm = task_map(task, nW, nWx, p.H, p.W, p.shift);
     __syncthreads();
-    load_tile_wg(Qs, p.qkv, ld, colq, tm, tid, p.scale);
-    load_tile_wg(Ks, p.qkv, ld, p.C + colq, tm, tid, 1.f);
-    load_tile_wg(Vs, p.qkv, ld, 2 * p.C + colq, tm, tid, 1.f);
-    load_tile_wg(Ds, p.dout, p.C, colq, tm, tid, 1.f);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) { put(Qs, rq[it], it, p.scale); put(Ks, rk[it], it, 1.f); put(Vs, rv[it], it, 1.f); put(Ds, rd[it], it, 1.f); }
     __syncthreads();
+    if (tt + 1 < p.tasks_per_wave && task + 1 < p.ntasks) fetch(task + 1);
     // ---- this wave's 16 query rows: S = (scale Q) K^T, dP = dO V^T, P = softmax, dS = P o (dP - rowsum(dP o P))
     f32x4 s[4], dp[4];
     {
