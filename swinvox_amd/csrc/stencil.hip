@@ -13,6 +13,8 @@
 // The forward epilogue stages the tile in LDS and stores whole channel rows per voxel (8-byte vectors).
 // bf16 operands, fp32 accumulate (these kernels serve set_math("bf16"); exact-fp32 parity runs use the generic engine).
 #include "common.h"
+#include <map>
+#include <mutex>
 
 namespace sv {
 
@@ -358,6 +360,19 @@ __global__ __launch_bounds__(256) void stencil3_wgrad_kernel(const StencilWArgsT
 
 using namespace sv;
 
+// resident 256-thread workgroups per CU of a kernel (cached per instantiation; 1 if the runtime cannot tell)
+static int resident_per_cu(const void* kernel) {
+  static std::mutex mu;
+  static std::map<const void*, int> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(kernel);
+  if (it != cache.end()) return it->second;
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
+  cache[kernel] = n;
+  return n;
+}
+
 static int stencil_check(int I, int D, int H, int W) {
   SV_REQUIRE(I > 0 && D % TZ == 0 && H % TY == 0 && W % TX == 0, "stencil3: grid %dx%dx%d must be a multiple of the 4x8x8 brick", D, H, W);
   return SV_OK;
@@ -387,10 +402,14 @@ extern "C" int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups,
     set_error("stencil3_fwd: unsupported (groups=%d, ntiles16=%d)", groups, ntiles16);
     return SV_ERR_INVALID;
   }
-  // persistent grid: as many workgroups as stay resident (LDS-bound: ~3 per CU with one channel group, 1 with three)
-  const int resident = 256 * (groups == 1 && ntiles16 == 1 ? 3 : 1);
-  const int blocks = ntiles < resident ? ntiles : resident;
+  // persistent grid: exactly as many workgroups as stay resident (asked from the runtime per instantiation: registers and
+  // LDS decide; a larger grid would queue workgroups behind the resident ones and unbalance the brick loop)
   SV_DISPATCH_ACT(act_dtype,
+    const int per_cu = groups == 1 && ntiles16 == 1 ? resident_per_cu((const void*)stencil3_fwd_kernel<1, 1, AT>)
+                     : groups == 3 ? resident_per_cu((const void*)stencil3_fwd_kernel<3, 1, AT>)
+                                   : resident_per_cu((const void*)stencil3_fwd_kernel<1, 3, AT>);
+    const int resident = 256 * per_cu;
+    const int blocks = ntiles < resident ? ntiles : resident;
     StencilArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, x_plane_stride, out_plane_stride, (const __bf16*)w_bf16, bias, static_cast<AT*>(out), ldc, col_off, cout,
                        static_cast<const AT*>(residual), ldr, stats, I, D, H, W, ntiles};
     if (groups == 1 && ntiles16 == 1) hipLaunchKernelGGL((stencil3_fwd_kernel<1, 1, AT>), dim3(blocks), dim3(256), 0, s, a);
@@ -414,10 +433,11 @@ extern "C" int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int group
   SV_REQUIRE((((uintptr_t)x | (uintptr_t)dy) & (act_dtype == SV_BF16 ? 7 : 15)) == 0, "stencil3_wgrad: operands must be aligned to 4 elements");
   SV_REQUIRE(groups == 1 || groups == 3, "stencil3_wgrad: unsupported groups=%d", groups);
   const int ntiles = I * (D / TZ) * (H / TY) * (W / TX);
-  const int resident = 256 * (groups == 1 ? 4 : 2);
-  const int blocks = ntiles < resident ? ntiles : resident;
   hipStream_t s = (hipStream_t)stream;
   SV_DISPATCH_ACT(act_dtype,
+    const int per_cu = groups == 1 ? resident_per_cu((const void*)stencil3_wgrad_kernel<1, AT>) : resident_per_cu((const void*)stencil3_wgrad_kernel<3, AT>);
+    const int resident = 256 * per_cu;
+    const int blocks = ntiles < resident ? ntiles : resident;
     StencilWArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, x_plane_stride, static_cast<const AT*>(dy), lddy, cout_load, dw, workspace, dbias, cout, cin, c_stride, c_valid,
                         I, D, H, W, ntiles};
     if (groups == 1) hipLaunchKernelGGL((stencil3_wgrad_kernel<1, AT>), dim3(blocks), dim3(256), 0, s, a);
