@@ -1,0 +1,72 @@
+"""The BASELINE configurations and config.py knobs around the default path: n_views 1 / 5 / 24, odd batches,
+single-stage Swin (USE_SWIN_T_MULTI_STAGE=False, encoder.py:77,140), a stage subset, no cross-view attention.  Whole train-mode
+step in exact-fp32 mode against the CPU oracle (loss and refined logits); bf16 math + bf16 storage checked for a close loss
+and finite gradients."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O  # noqa: E402
+import swinvox_amd as S  # noqa: E402
+from swinvox_amd.models import Decoder, Encoder, Merger, Refiner  # noqa: E402
+
+bce = torch.nn.functional.binary_cross_entropy_with_logits
+CASES = [dict(B=2, V=1), dict(B=1, V=24), dict(B=3, V=5), dict(B=2, V=2, multi=False), dict(B=2, V=3, cva=False), dict(B=2, V=2, stages=[1, 3])]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()).replace(" ", ""))
+def test_config_variant_matches_the_oracle(dev, case):
+    B, V = case["B"], case["V"]
+    ocfg, pcfg = O.default_cfg(), S.default_cfg()
+    for c in (ocfg, pcfg):
+        if "multi" in case:
+            c.NETWORK.USE_SWIN_T_MULTI_STAGE = case["multi"]
+        if "cva" in case:
+            c.NETWORK.USE_CROSS_VIEW_ATTENTION = case["cva"]
+        if "stages" in case:
+            c.NETWORK.SWIN_T_STAGES = case["stages"]
+    torch.manual_seed(0)
+    onets = [O.Encoder(ocfg), O.Decoder(ocfg), O.Merger(ocfg), O.Refiner(ocfg)]
+    for i, n in enumerate(onets):
+        O.seeded_weights_(n, seed=50 + i)
+        n.train()
+        for m in n.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            if isinstance(m, O.model.SwinBlock):
+                m.dp = 0.0
+    pnets = [Encoder(pcfg), Decoder(pcfg), Merger(pcfg), Refiner(pcfg)]
+    for p, o in zip(pnets, onets):
+        p.load_state_dict(o.state_dict())       # strict: the variant has exactly the reference's parameters
+        p.to(dev).train()
+        p.stochastic = False
+    g = torch.Generator().manual_seed(1)
+    x = (0.5 * torch.randn(B, V, 3, 224, 224, generator=g)).clamp(-1, 1)
+    gt = (torch.rand(B, 32, 32, 32, generator=g) < 0.1).float()
+    with torch.no_grad():
+        total_o, _, _, _, refined_o = O.train_step_loss(onets, ocfg, x, gt)
+    out = {}
+    for mode in ("f32", "bf16"):
+        S.set_math(mode)
+        if mode == "bf16":
+            S.set_storage("bf16")
+        try:
+            for p in pnets:
+                p.zero_grad(set_to_none=True)
+            raw, vol = pnets[1](pnets[0](x.to(dev)))
+            merged = pnets[2](raw, vol)
+            refined = pnets[3](merged)
+            total = bce(merged, gt.to(dev)) + bce(refined, gt.to(dev))
+            total.backward()
+            finite = all(bool(torch.isfinite(p.grad).all()) for n in pnets for p in n.parameters() if p.grad is not None)
+            n_grads = sum(p.grad is not None for n in pnets for p in n.parameters())
+            out[mode] = (float(total.detach()), float((refined.detach().cpu() - refined_o).abs().max()), finite, n_grads)
+        finally:
+            S.set_math("f32")
+    l32, e32, f32, n32 = out["f32"]
+    l16, _, f16, _ = out["bf16"]
+    ref = float(total_o)
+    assert n32 == sum(1 for n in pnets for _ in n.parameters())           # every parameter of the variant received a gradient
+    assert abs(l32 - ref) < 1e-3 and e32 < 2e-3 * max(1.0, float(refined_o.abs().max())) and f32      # fp32: 1e-3 (north_star)
+    assert f16 and abs(l16 - ref) < 3e-2 * max(1.0, abs(ref))
