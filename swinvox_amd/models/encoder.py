@@ -155,10 +155,10 @@ class Encoder(HipModule):
         cat = empty(I * 49, 512, like=img)                                 # [resnet 256 | swin 256] concat buffer
         main = torch.cuda.current_stream()
         side = ops.side_stream(img.device) if ops.overlap_enabled() else main
-        side.wait_stream(main)                                             # fork: the Swin branch runs beside the ResNet trunk
+        side.wait_stream(main)                                             # fork: the Swin backbone runs beside the ResNet trunk
+        ready = []
         with torch.cuda.stream(side):
-            neck = self._swin_branch_fwd(img, cat, I, tr, sto, seeds, multi)
-        swin_tape = neck.pop()
+            feats, swin_tape = swin_forward(self.swin_transformer, img, I, tr, sto, seeds, ready)
         # ---- ResNet trunk
         x, g, c_stem = self._stem_fwd(images, I, tr)
         mp = empty(I * 56 * 56, 64, like=x)
@@ -174,6 +174,9 @@ class Encoder(HipModule):
         rr = empty(I * 196, 256, like=x)
         ops.linear_fwd(res_feat, I * 196, self._s_rr, self.resnet_reduce.weight, rr, bias=self.resnet_reduce.bias)
         call("sv_avgpool2_fwd", ptr(rr), ptr(cat), I, 14, 14, 256, 512, 0)
+        # the multi-stage neck (stage reduces + stride-2 conv chains) belongs to the MAIN stream: the ResNet trunk is the
+        # shorter branch, and each stage output is consumed as soon as its event fires while the backbone computes the next stage
+        neck = self._swin_neck_fwd(feats, ready, cat, I, tr, multi, main)
         main.wait_stream(side)                                             # join
         # ---- cross-view attention
         c_cva = None
@@ -191,13 +194,15 @@ class Encoder(HipModule):
         tape = (B, V, c_stem, mp_idx, c_blocks, res_feat, rr, swin_tape, neck, c_cva, c_post) if save else None
         return ops.to_f32(out), tape
 
-    def _swin_branch_fwd(self, img, cat, I, tr, sto, seeds, multi):
-        """Swin backbone + multi-stage neck -> cat[:, 256:]; returns the neck tape with the backbone tape appended."""
-        feats, swin_tape = swin_forward(self.swin_transformer, img, I, tr, sto, seeds)
+    def _swin_neck_fwd(self, feats, ready, cat, I, tr, multi, stream):
+        """stage-head outputs of the Swin backbone -> cat[:, 256:] (runs on `stream`, waiting for each output's event);
+        returns the neck tape."""
+        img = feats[0] if isinstance(feats, list) else feats
         neck = []
         if multi:
             outs = []
             for k, f in enumerate(feats):
+                stream.wait_event(ready[k])
                 hw = self.swin_transformer.out_spatial[k]
                 red = empty(I * hw * hw, 256, like=img)
                 ops.linear_fwd(f, I * hw * hw, self._s_red[k], self.swin_stage_reduces[k].weight, red, bias=self.swin_stage_reduces[k].bias)
@@ -215,9 +220,9 @@ class Encoder(HipModule):
                  ptr(cat_s), I * 49, 256, 512)
         else:
             f = feats if not isinstance(feats, list) else feats[-1]
+            stream.wait_event(ready[-1])
             ops.linear_fwd(f, I * 49, self._s_red1, self.swin_reduce.weight, cat, ldc=512, col_off=256, bias=self.swin_reduce.bias)
             neck.append((f, None, None))
-        neck.append(swin_tape)
         return neck
 
     def _bwd(self, tape, grads, in_needs, dout):
@@ -236,23 +241,31 @@ class Encoder(HipModule):
         main = torch.cuda.current_stream()
         side = ops.side_stream(dcat.device) if ops.overlap_enabled() else main
         side.wait_stream(main)                                             # fork (dcat and the zeroed gradient store are ready)
+        dcat_s = dcat[:, 256:]
+        dready = None
+        if multi:
+            # neck backward on the MAIN stream, last stage first (the order the backbone backward consumes the gradients in);
+            # the side stream waits for each stage's event and meanwhile works on the later stages
+            dfeats, dready = [None] * len(neck), [None] * len(neck)
+            for k in reversed(range(len(neck))):
+                f, red, cc = neck[k]
+                hw = self.swin_transformer.out_spatial[k]
+                d, ld = dcat_s, 512
+                for cba, c in zip(reversed(self._chains[k]), reversed(cc)):
+                    d = cba.backward(c, d, ld, grads)
+                    ld = 256
+                conv = self.swin_stage_reduces[k]
+                sp = self._s_red[k]
+                rows = I * hw * hw
+                sp.wgrad(d, f, rows, (1, 1, 1), grads[conv.weight], lddy=ld, db=grads[conv.bias])
+                df = empty(rows, sp.cin, like=dout)
+                sp.dgrad(d, rows, (1, 1, 1), sp.pack_dgrad(conv.weight), df, lddy=ld)
+                dfeats[k] = df
+                dready[k] = torch.cuda.Event()
+                dready[k].record(main)
         with torch.cuda.stream(side):
-            dcat_s = dcat[:, 256:]
             if multi:
-                dfeats = []
-                for k, (f, red, cc) in enumerate(neck):
-                    hw = self.swin_transformer.out_spatial[k]
-                    d, ld = dcat_s, 512
-                    for cba, c in zip(reversed(self._chains[k]), reversed(cc)):
-                        d = cba.backward(c, d, ld, grads)
-                        ld = 256
-                    conv = self.swin_stage_reduces[k]
-                    sp = self._s_red[k]
-                    rows = I * hw * hw
-                    sp.wgrad(d, f, rows, (1, 1, 1), grads[conv.weight], lddy=ld, db=grads[conv.bias])
-                    df = empty(rows, sp.cin, like=dout)
-                    sp.dgrad(d, rows, (1, 1, 1), sp.pack_dgrad(conv.weight), df, lddy=ld)
-                    dfeats.append(df)
+                pass
             else:
                 f = neck[0][0]
                 sp = self._s_red1
@@ -263,7 +276,7 @@ class Encoder(HipModule):
                 for i in range(len(dfeats) - 1):   # unused heads of the single-stage path receive zero gradient
                     hw, ch = self.swin_transformer.out_spatial[i], self.swin_transformer.out_channels[i]
                     dfeats[i] = zeros(I * hw * hw, ch, like=dout)
-            swin_backward(self.swin_transformer, swin_tape, dfeats, I, grads)
+            swin_backward(self.swin_transformer, swin_tape, dfeats, I, grads, dready)
         # ---- ResNet branch
         drr = empty(I * 196, 256, like=dout)
         call("sv_avgpool2_bwd", ptr(dcat), ptr(drr), I, 14, 14, 256, 512, 0)

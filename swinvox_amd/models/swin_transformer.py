@@ -202,8 +202,10 @@ def block_backward(blk: SwinBlock, ctx, dx2, grads):
     return dx1
 
 
-def swin_forward(st: SwinTransformer, img_nhwc, I, training, stochastic, seeds):
-    """img_nhwc [I,224,224,3] -> list of stage-head outputs [I*HW, C] (NHWC rows) + tape."""
+def swin_forward(st: SwinTransformer, img_nhwc, I, training, stochastic, seeds, ready=None):
+    """img_nhwc [I,224,224,3] -> list of stage-head outputs [I*HW, C] (NHWC rows) + tape.  `ready` (optional list) receives
+    one event per head output, recorded on the current stream as soon as that output is complete, so that another stream
+    can consume the early stages while the later ones are still being computed."""
     bb = st.model
     pe = bb.patch_embed
     S = st.img_size
@@ -245,6 +247,10 @@ def swin_forward(st: SwinTransformer, img_nhwc, I, training, stochastic, seeds):
             call("sv_ln_image_fwd", ptr(x), ptr(wt), ptr(bt), ptr(y), ptr(mr), ptr(ws), I, L, float(ln.eps), float(p), seed)
             tape["heads"].append((si, head_i, x, wt, mr, p, seed, L))
             feats.append(y)
+            if ready is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                ready.append(ev)
             head_i += 1
     return feats, tape
 
@@ -254,8 +260,10 @@ def hipws(I, L):
     return hip.load().sv_ln_image_workspace_floats(I, L)
 
 
-def swin_backward(st: SwinTransformer, tape, dfeats, I, grads):
-    """dfeats: list of gradients wrt the stage-head outputs ([I*HW, C]).  No gradient wrt the image is produced."""
+def swin_backward(st: SwinTransformer, tape, dfeats, I, grads, ready=None):
+    """dfeats: list of gradients wrt the stage-head outputs ([I*HW, C]).  No gradient wrt the image is produced.
+    `ready` (optional): one event per entry of dfeats, awaited right before that gradient is first read (the producer may
+    still be working on the earlier stages' gradients on another stream)."""
     bb = st.model
     stages = bb.stages()
     head_of = {si: (hi, xs, wt, mr, p, seed, L) for (si, hi, xs, wt, mr, p, seed, L) in tape["heads"]}
@@ -264,6 +272,8 @@ def swin_backward(st: SwinTransformer, tape, dfeats, I, grads):
         stage = stages[si]
         if si in head_of:
             hi, xs, wt, mr, p, seed, L = head_of[si]
+            if ready is not None and ready[hi] is not None:
+                torch.cuda.current_stream().wait_event(ready[hi])
             ln = st.layer_norm[hi]
             Cs, Hs = stage.dim, stage.res
             dxe = empty(I * Hs * Hs, Cs, like=xs)
