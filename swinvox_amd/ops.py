@@ -389,7 +389,8 @@ def side_stream(dev) -> "torch.cuda.Stream":
     tensors read by the side branch must stay referenced until the join (callers keep them in locals / the tape)."""
     key = (dev.type, dev.index)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=dev)
+        # high priority: the Swin backbone that runs here is the longer of the two encoder branches (measured +0.35 %)
+        _SIDE[key] = torch.cuda.Stream(device=dev, priority=-1)
     return _SIDE[key]
 
 
