@@ -27,6 +27,30 @@ __device__ __forceinline__ void st4f(__bf16* p, float4 v) {
   b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
   *reinterpret_cast<bf16x4*>(p) = b;
 }
+// N = 4 or 8 consecutive activations <-> float registers (8 x bf16 = one 16-byte access)
+template <int N, typename T> __device__ __forceinline__ void ldnf(const T* p, float (&v)[N]) {
+  if constexpr (N == 8 && sizeof(T) == 2) {
+    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+    const b8 b = *reinterpret_cast<const b8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)b[j];
+  } else {
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) { const float4 f = ld4f(p + 4 * q); v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w; }
+  }
+}
+template <int N, typename T> __device__ __forceinline__ void stnf(T* p, const float (&v)[N]) {
+  if constexpr (N == 8 && sizeof(T) == 2) {
+    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+    b8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[j];
+    *reinterpret_cast<b8*>(p) = b;
+  } else {
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) st4f(p + 4 * q, make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]));
+  }
+}
 // raw 4-element vectors (no conversion) for the MFMA operand loaders
 template <typename T> struct V4;
 template <> struct V4<float> {

@@ -182,6 +182,104 @@ __device__ __forceinline__ void decode_row(int m, int c0, int c1, int c2, int& n
   d_ = t % c0; n_ = t / c0;
 }
 
+// cooperative row pass of the tile epilogue (see tile_epilogue): thread (cr, cw) owns CV consecutive columns of row cr + k*CRPP
+template <bool BF16, bool TCONV, typename TL, typename AT, int CV>
+__device__ __forceinline__ void epilogue_rows(const IGemmArgs& p, const ClassInfo& ci, int cnt0, int cnt1, int cnt2, const float* Cs, float* red,
+                                              int row0, int col0, int Mrows) {
+  constexpr int BM = TL::BM, BN = TL::BN, NTHR = TL::NTHR, NW = TL::NW, LDC = BN + 4;
+  constexpr int CW = BN / CV, CRPP = NTHR / CW, CPASS = (BM + CRPP - 1) / CRPP;   // 96-wide tile: idle threads past CRPP * CW
+  const Geom& g = p.g;
+  const Epi& e = p.e;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  AT* __restrict__ Y = static_cast<AT*>(p.y);
+  const int cw = tid % CW, cr = tid / CW;
+  const int n0 = col0 + cw * CV;
+  const bool vec_out = ((e.ldc | e.col_off | g.Co) & (CV - 1)) == 0 && (!e.residual || (e.ldr & (CV - 1)) == 0);
+  float bias[CV];
+#pragma unroll
+  for (int j = 0; j < CV; ++j) bias[j] = (e.bias && n0 + j < g.Co) ? e.bias[n0 + j] : 0.f;
+  float s1[CV], s2[CV];
+#pragma unroll
+  for (int j = 0; j < CV; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  if (n0 < g.Co && cr < CRPP) {
+#pragma unroll 2
+    for (int ps_ = 0; ps_ < CPASS; ++ps_) {
+      const int row = cr + CRPP * ps_;
+      const int m = row0 + row;
+      if (row >= BM || m >= Mrows) break;
+      int pos = m;
+      if constexpr (TCONV) {
+        int n_, d_, h_, w_;
+        decode_row(m, cnt0, cnt1, cnt2, n_, d_, h_, w_);
+        const int od = ci.o0[0] + g.sd * d_, oh = ci.o0[1] + g.sh * h_, ow = ci.o0[2] + g.sw * w_;
+        pos = ((n_ * g.Do + od) * g.Ho + oh) * g.Wo + ow;
+      }
+      float v[CV];
+#pragma unroll
+      for (int q = 0; q < CV / 4; ++q) {
+        const float4 c = *reinterpret_cast<const float4*>(Cs + row * LDC + cw * CV + q * 4);
+        v[q * 4] = c.x + bias[q * 4]; v[q * 4 + 1] = c.y + bias[q * 4 + 1]; v[q * 4 + 2] = c.z + bias[q * 4 + 2]; v[q * 4 + 3] = c.w + bias[q * 4 + 3];
+      }
+      const size_t o = (size_t)pos * e.ldc + e.col_off + n0;
+      const float sc = (e.residual && e.row_scale) ? e.row_scale[pos / e.rows_per_scale] : 1.f;
+      if (vec_out) {   // Co % CV == 0 => the whole vector is in range
+        if (e.act_grad_src) {
+          float a[CV];
+          ldnf<CV>(static_cast<const AT*>(e.act_grad_src) + o, a);
+#pragma unroll
+          for (int j = 0; j < CV; ++j) v[j] *= act_grad_t<BF16>(a[j], e.act_grad_kind, e.slope);
+        }
+        if (e.pre_act) stnf<CV>(static_cast<AT*>(e.pre_act) + o, v);
+#pragma unroll
+        for (int j = 0; j < CV; ++j) v[j] = apply_act_t<BF16>(v[j], e.act, e.slope);
+        if (e.residual) {
+          float r[CV];
+          ldnf<CV>(static_cast<const AT*>(e.residual) + (size_t)pos * e.ldr + n0, r);
+#pragma unroll
+          for (int j = 0; j < CV; ++j) v[j] = r[j] + sc * v[j];
+        }
+        stnf<CV>(Y + o, v);
+#pragma unroll
+        for (int j = 0; j < CV; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CV; ++j) {
+          if (n0 + j < g.Co) {
+            float t = v[j];
+            if (e.act_grad_src) t *= act_grad_t<BF16>(ldf(static_cast<const AT*>(e.act_grad_src) + o + j), e.act_grad_kind, e.slope);
+            if (e.pre_act) stf(static_cast<AT*>(e.pre_act) + o + j, t);
+            t = apply_act_t<BF16>(t, e.act, e.slope);
+            if (e.residual) t = ldf(static_cast<const AT*>(e.residual) + (size_t)pos * e.ldr + n0 + j) + sc * t;
+            stf(Y + o + j, t);
+            s1[j] += t; s2[j] += t * t;
+          }
+        }
+      }
+    }
+  }
+  if (e.stats) {  // per-channel sum / sumsq of what was stored: lanes sharing a column group, then the waves, then ONE
+                  // double atomic per column per workgroup into one of SV_BN_SLOTS accumulator slots (spreads contention)
+#pragma unroll
+    for (int j = 0; j < CV; ++j) {
+#pragma unroll
+      for (int o = CW; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+    if ((lane / CW) == 0 || CW >= 64) {
+#pragma unroll
+      for (int j = 0; j < CV; ++j) { red[(wave * BN + cw * CV + j) * 2] = s1[j]; red[(wave * BN + cw * CV + j) * 2 + 1] = s2[j]; }
+    }
+    __syncthreads();
+    if (tid < BN && col0 + tid < g.Co) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+      double* st = e.stats + (size_t)((row0 / BM) % SV_BN_SLOTS) * 2 * g.Co;
+      atomicAdd(st + col0 + tid, (double)a);
+      atomicAdd(st + g.Co + col0 + tid, (double)b);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // tile epilogue shared by the gather kernels: accumulators -> LDS tile -> cooperative, row-contiguous vector reads/writes with
 // the fused bias / activation(-gradient) / residual / pre-activation copy / per-channel statistics.  Every wave must have
@@ -207,86 +305,14 @@ __device__ __forceinline__ void tile_epilogue(const IGemmArgs& p, const ClassInf
           Cs[((wm * MT + mt) * 16 + lg * 4 + j) * LDC + (wn * NT + nt) * 16 + lr] = acc[mt][nt][j];
   }
   __syncthreads();
-  constexpr int C4 = BN / 4, CRPP = NTHR / C4, CPASS = (BM + CRPP - 1) / CRPP;   // 96-wide tile: 21 rows per pass, 8 idle threads
-  const int c4 = tid % C4, cr = tid / C4;
-  const int n0 = col0 + c4 * 4;
-  const bool vec_out = ((e.ldc | e.col_off | g.Co) & 3) == 0 && (!e.residual || (e.ldr & 3) == 0);
-  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-  if (e.bias) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) if (n0 + j < g.Co) bias4[j] = e.bias[n0 + j];
+  // row pass: CV consecutive columns per thread.  bf16 storage with 8-aligned rows moves 16 bytes per lane (half the
+  // global-memory instructions, 1 KB per wave store); everything else keeps 4 columns per thread.
+  if constexpr (sizeof(AT) == 2 && BN % 8 == 0) {
+    const bool wide = ((e.ldc | e.col_off | g.Co) & 7) == 0 && (!e.residual || (e.ldr & 7) == 0) &&
+                      (((uintptr_t)p.y | (uintptr_t)e.residual | (uintptr_t)e.pre_act | (uintptr_t)e.act_grad_src) & 15) == 0;
+    if (wide) { epilogue_rows<BF16, TCONV, TL, AT, 8>(p, ci, cnt0, cnt1, cnt2, Cs, red, row0, col0, Mrows); return; }
   }
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (n0 < g.Co && cr < CRPP) {
-#pragma unroll 2
-    for (int ps_ = 0; ps_ < CPASS; ++ps_) {
-      const int row = cr + CRPP * ps_;
-      const int m = row0 + row;
-      if (row >= BM || m >= Mrows) break;
-      int pos = m;
-      if constexpr (TCONV) {
-        int n_, d_, h_, w_;
-        decode_row(m, cnt0, cnt1, cnt2, n_, d_, h_, w_);
-        const int od = ci.o0[0] + g.sd * d_, oh = ci.o0[1] + g.sh * h_, ow = ci.o0[2] + g.sw * w_;
-        pos = ((n_ * g.Do + od) * g.Ho + oh) * g.Wo + ow;
-      }
-      const float4 c = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
-      float v[4] = {c.x + bias4[0], c.y + bias4[1], c.z + bias4[2], c.w + bias4[3]};
-      const size_t o = (size_t)pos * e.ldc + e.col_off + n0;
-      const float sc = (e.residual && e.row_scale) ? e.row_scale[pos / e.rows_per_scale] : 1.f;
-      if (vec_out) {   // Co % 4 == 0 => the whole float4 is in range
-        if (e.act_grad_src) {
-          const float4 a = ld4f(static_cast<const AT*>(e.act_grad_src) + o);
-          v[0] *= act_grad_t<BF16>(a.x, e.act_grad_kind, e.slope); v[1] *= act_grad_t<BF16>(a.y, e.act_grad_kind, e.slope);
-          v[2] *= act_grad_t<BF16>(a.z, e.act_grad_kind, e.slope); v[3] *= act_grad_t<BF16>(a.w, e.act_grad_kind, e.slope);
-        }
-        if (e.pre_act) st4f(static_cast<AT*>(e.pre_act) + o, make_float4(v[0], v[1], v[2], v[3]));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = apply_act_t<BF16>(v[j], e.act, e.slope);
-        if (e.residual) {
-          const float4 r = ld4f(static_cast<const AT*>(e.residual) + (size_t)pos * e.ldr + n0);
-          v[0] = r.x + sc * v[0]; v[1] = r.y + sc * v[1]; v[2] = r.z + sc * v[2]; v[3] = r.w + sc * v[3];
-        }
-        st4f(Y + o, make_float4(v[0], v[1], v[2], v[3]));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (n0 + j < g.Co) {
-            float t = v[j];
-            if (e.act_grad_src) t *= act_grad_t<BF16>(ldf(static_cast<const AT*>(e.act_grad_src) + o + j), e.act_grad_kind, e.slope);
-            if (e.pre_act) stf(static_cast<AT*>(e.pre_act) + o + j, t);
-            t = apply_act_t<BF16>(t, e.act, e.slope);
-            if (e.residual) t = ldf(static_cast<const AT*>(e.residual) + (size_t)pos * e.ldr + n0 + j) + sc * t;
-            stf(Y + o + j, t);
-            s1[j] += t; s2[j] += t * t;
-          }
-        }
-      }
-    }
-  }
-  if (e.stats) {  // per-channel sum / sumsq of what was stored: lanes sharing a column group, then the 4 waves, then ONE
-                  // double atomic per column per workgroup into one of SV_BN_SLOTS accumulator slots (spreads contention)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int o = C4; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
-    }
-    if ((lane / C4) == 0 || C4 >= 64) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { red[(wave * BN + c4 * 4 + j) * 2] = s1[j]; red[(wave * BN + c4 * 4 + j) * 2 + 1] = s2[j]; }
-    }
-    __syncthreads();
-    if (tid < BN && col0 + tid < g.Co) {
-      float a = 0.f, b = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
-      double* st = e.stats + (size_t)((row0 / BM) % SV_BN_SLOTS) * 2 * g.Co;
-      atomicAdd(st + col0 + tid, (double)a);
-      atomicAdd(st + g.Co + col0 + tid, (double)b);
-    }
-  }
+  epilogue_rows<BF16, TCONV, TL, AT, 4>(p, ci, cnt0, cnt1, cnt2, Cs, red, row0, col0, Mrows);
 }
 
 // ------------------------------------------------------------------------------------------------
