@@ -82,6 +82,8 @@ __device__ __forceinline__ void store4(float* dst, bf16x8 v) {   // never select
 }
 
 // ---- MFMA over one K-step slab, operands stored [row][k] (k contiguous) ---------------------------
+// The B fragment goes in as the MFMA's first operand: the accumulator then is the TRANSPOSED 16x16 block, i.e. lane (lr, lg)
+// holds C[row = lr][cols lg*4 .. lg*4+3] - four consecutive columns, which the epilogue stages with one 16-byte LDS write.
 template <bool BF16, int MT, int NT>
 __device__ __forceinline__ void mma_slab(const typename Cfg<BF16>::T* As, const typename Cfg<BF16>::T* Bs,
                                          int arow0, int brow0, int lane, f32x4 (&acc)[MT][NT]) {
@@ -98,7 +100,7 @@ __device__ __forceinline__ void mma_slab(const typename Cfg<BF16>::T* As, const 
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt], a[mt], acc[mt][nt], 0, 0, 0);
     }
   } else {
 #pragma unroll
@@ -111,7 +113,7 @@ __device__ __forceinline__ void mma_slab(const typename Cfg<BF16>::T* As, const 
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt], a[mt], acc[mt][nt], 0, 0, 0);
     }
   }
 }
@@ -300,9 +302,8 @@ __device__ __forceinline__ void tile_epilogue(const IGemmArgs& p, const ClassInf
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          Cs[((wm * MT + mt) * 16 + lg * 4 + j) * LDC + (wn * NT + nt) * 16 + lr] = acc[mt][nt][j];
+        // accumulator layout of mma_slab: row lr, columns lg*4 .. lg*4+3
+        *reinterpret_cast<f32x4*>(Cs + ((wm * MT + mt) * 16 + lr) * LDC + (wn * NT + nt) * 16 + lg * 4) = acc[mt][nt];
   }
   __syncthreads();
   // row pass: CV consecutive columns per thread.  bf16 storage with 8-aligned rows moves 16 bytes per lane (half the
