@@ -721,16 +721,15 @@ __global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const bf16x8 b = *reinterpret_cast<const bf16x8*>(Vt + (nt * 16 + lr) * LDP_H + ks * 32 + lg * 8);
-        o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, o[nt], 0, 0, 0);
-      }
+        o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, o[nt], 0, 0, 0);   // operands swapped: the accumulator is the
+      }                                                                              // transposed block, O[q = lr][d = lg*4 + j]
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int q = wave * 16 + lg * 4 + j;
+    {   // four consecutive channels per lane: one vector store per 16-column block instead of four 2-byte scatters
+      const int q = wave * 16 + lr;
       if (q < WT) {
-        AT* dst = p.out + (size_t)tm.row(q) * p.C + colq;
-        stf(dst + lr, o[0][j]);
-        stf(dst + 16 + lr, o[1][j]);
+        AT* dst = p.out + (size_t)tm.row(q) * p.C + colq + lg * 4;
+        st4f(dst, make_float4(o[0][0], o[0][1], o[0][2], o[0][3]));
+        st4f(dst + 16, make_float4(o[1][0], o[1][1], o[1][2], o[1][3]));
       }
     }
   }
@@ -842,19 +841,22 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
         const bf16x8 bd = tr_frag(Ds, LDQ_H, ks * 32, nt * 16, lane);        // dO[q][d]
         const bf16x8 bq = tr_frag(Qs, LDQ_H, ks * 32, nt * 16, lane);        // (scale Q)[q][d]
         const bf16x8 bk = tr_frag(Ks, LDQ_H, ks * 32, nt * 16, lane);        // K[key][d]
-        av[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pT, bd, av[nt], 0, 0, 0);
-        ak[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sT, bq, ak[nt], 0, 0, 0);
-        aq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sR, bk, aq[nt], 0, 0, 0);
+        // operands swapped: the accumulators are the transposed blocks, X[row = lr][d = lg*4 + j] (vector stores below)
+        av[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bd, pT, av[nt], 0, 0, 0);
+        ak[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, sT, ak[nt], 0, 0, 0);
+        aq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk, sR, aq[nt], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int t = wave * 16 + lg * 4 + j;       // a key row for dV / dK, a query row for dQ
+    {
+      const int t = wave * 16 + lr;               // a key row for dV / dK, a query row for dQ
       if (t < WT) {
-        AT* dst = p.dqkv + (size_t)tm.row(t) * ld + colq;
-        stf(dst + lr, aq[0][j] * p.scale); stf(dst + 16 + lr, aq[1][j] * p.scale);
-        stf(dst + p.C + lr, ak[0][j]); stf(dst + p.C + 16 + lr, ak[1][j]);
-        stf(dst + 2 * p.C + lr, av[0][j]); stf(dst + 2 * p.C + 16 + lr, av[1][j]);
+        AT* dst = p.dqkv + (size_t)tm.row(t) * ld + colq + lg * 4;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          st4f(dst + nt * 16, make_float4(aq[nt][0] * p.scale, aq[nt][1] * p.scale, aq[nt][2] * p.scale, aq[nt][3] * p.scale));
+          st4f(dst + p.C + nt * 16, make_float4(ak[nt][0], ak[nt][1], ak[nt][2], ak[nt][3]));
+          st4f(dst + 2 * p.C + nt * 16, make_float4(av[nt][0], av[nt][1], av[nt][2], av[nt][3]));
+        }
       }
     }
   }
