@@ -94,13 +94,10 @@ struct StencilArgsT {                         // AT = storage element of the act
 template <int G, int NT, typename AT>
 __global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgsT<AT> p) {
   constexpr int C = 16 * G, KTOT = 27 * C, KPAD = (KTOT + 31) / 32 * 32, NSTEP = KPAD / 32;
-  constexpr int NCOL = NT * 16, LDC = NCOL + 1;
-  constexpr int XS_BYTES = HPOS * C * 2, CS_BYTES = NVOX * LDC * 4;
-  __shared__ __attribute__((aligned(16))) char xc[XS_BYTES > CS_BYTES ? XS_BYTES : CS_BYTES];   // halo brick, then the output tile
+  __shared__ __attribute__((aligned(16))) char xc[HPOS * C * 2];   // halo brick
   __shared__ __attribute__((aligned(16))) __bf16 Ws[NT * 16 * KPAD];
   __shared__ float red[16 * 16 * 2];
   __bf16* Xs = reinterpret_cast<__bf16*>(xc);
-  float* Cs = reinterpret_cast<float*>(xc);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
 
@@ -113,9 +110,12 @@ __global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgsT<AT
   }
   const int cs4 = (p.cout + 3) & ~3;
   const bool vec_out = p.out_plane != 0 || (p.ldc & 3) == 0 && (p.col_off & 3) == 0 && p.col_off + cs4 <= p.ldc && (!p.residual || ((p.ldr & 3) == 0 && cs4 <= p.ldr));
-  const int sn = tid & 15, srg = tid >> 4;           // statistics: column sn, voxel group srg (16 voxels)
-  const float sbias = (p.bias && sn < p.cout) ? p.bias[sn] : 0.f;
-  float st1 = 0.f, st2 = 0.f;
+  // this lane's output columns: n = nt*16 + lg*4 + j (the accumulators are transposed blocks, see the MFMA loop)
+  float bias4[NT][4], st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int n = nt * 16 + lg * 4 + j; bias4[nt][j] = (p.bias && n < p.cout) ? p.bias[n] : 0.f; }
 
   HaloRegs<G, AT> hr;
   int tile = xcd_first_tile();
@@ -150,31 +150,27 @@ __global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgsT<AT
       for (int mt = 0; mt < 4; ++mt) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xs + (abase[mt] + off) * C + c);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt], a, acc[mt][nt], 0, 0, 0);   // B first: transposed block
       }
     }
-    __syncthreads();                                 // every wave is done reading the brick: the tile may overwrite it
-    // accumulators -> Cs[voxel][column]; C element (row = lg*4 + j -> voxel, col = lr -> output channel)
+    // With the weight fragment as the MFMA's first operand the accumulator block is transposed: lane (lr, lg) holds voxel
+    // row lr = (y = 2mt + (lr >> 3), x = lr & 7) of z-slice `wave`, columns nt*16 + lg*4 .. +3 - four consecutive channels,
+    // stored straight from the registers as one vector (no LDS staging of the tile, no extra barriers).
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt) {
+      const size_t pos = (((size_t)t.img * p.D + t.z0 + wave) * p.H + t.y0 + 2 * mt + yy) * p.W + t.x0 + xx;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n0 = nt * 16 + lg * 4;
+        if (n0 >= cs4) continue;
+        float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = lg * 4 + j;
-          const int vid = (wave * TY + 2 * mt + (r >> 3)) * TX + (r & 7);
-          Cs[vid * LDC + nt * 16 + lr] = acc[mt][nt][j];
+        for (int j = 0; j < 4; ++j) v[j] = (n0 + j < p.cout) ? acc[mt][nt][j] + bias4[nt][j] : 0.f;
+        if (NT == 1 && p.stats) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { st1[j] += v[j]; st2[j] += v[j] * v[j]; }
         }
-    __syncthreads();
-    {  // one voxel per thread: whole channel row (+ bias, + residual)
-      const int vz = tid >> 6, vy = (tid >> 3) & 7, vx = tid & 7;
-      const size_t pos = (((size_t)t.img * p.D + t.z0 + vz) * p.H + t.y0 + vy) * p.W + t.x0 + vx;
-      const float* crow = Cs + tid * LDC;
-      if (vec_out) {
-        for (int n0 = 0; n0 < cs4; n0 += 4) {
-          float v[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (n0 + j < p.cout) ? crow[n0 + j] + (p.bias ? p.bias[n0 + j] : 0.f) : 0.f;
+        if (vec_out) {
           if (p.residual) {
             const float4 rv = ld4f(p.residual + pos * p.ldr + n0);
             v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
@@ -185,30 +181,37 @@ __global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgsT<AT
           } else {
             st4f(p.out + pos * p.ldc + p.col_off + n0, make_float4(v[0], v[1], v[2], v[3]));
           }
-        }
-      } else {
-        for (int n = 0; n < p.cout; ++n) {
-          float v = crow[n] + (p.bias ? p.bias[n] : 0.f);
-          if (p.residual) v += ldf(p.residual + pos * p.ldr + n);
-          stf(p.out + pos * p.ldc + p.col_off + n, v);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (n0 + j < p.cout) {
+              float r = v[j];
+              if (p.residual) r += ldf(p.residual + pos * p.ldr + n0 + j);
+              stf(p.out + pos * p.ldc + p.col_off + n0 + j, r);
+            }
+          }
         }
       }
     }
-    if (NT == 1 && p.stats && sn < p.cout) {         // per-channel sum / sum of squares of the stored values
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { const float v = Cs[(srg * 16 + k) * LDC + sn] + sbias; st1 += v; st2 += v * v; }
-    }
-    __syncthreads();                                 // the tile is consumed: the next brick may land in LDS
+    __syncthreads();                                 // every wave is done reading the brick: the next one may land in LDS
     if (next < p.ntiles) hr.store(Xs, tid);
     __syncthreads();
   }
-  if (NT == 1 && p.stats) {
-    red[(srg * 16 + sn) * 2] = st1; red[(srg * 16 + sn) * 2 + 1] = st2;
+  if (NT == 1 && p.stats) {                          // per-channel sum / sum of squares of the stored values (without residual)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { st1[j] += __shfl_xor(st1[j], o, 64); st2[j] += __shfl_xor(st2[j], o, 64); }
+    }
+    if (lr == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { red[(wave * 16 + lg * 4 + j) * 2] = st1[j]; red[(wave * 16 + lg * 4 + j) * 2 + 1] = st2[j]; }
+    }
     __syncthreads();
     if (tid < 16 && tid < p.cout) {
       float a = 0.f, b = 0.f;
 #pragma unroll
-      for (int g2 = 0; g2 < 16; ++g2) { a += red[(g2 * 16 + tid) * 2]; b += red[(g2 * 16 + tid) * 2 + 1]; }
+      for (int w = 0; w < 4; ++w) { a += red[(w * 16 + tid) * 2]; b += red[(w * 16 + tid) * 2 + 1]; }
       double* st = p.stats + (size_t)(blockIdx.x % SV_BN_SLOTS) * 2 * p.cout;
       atomicAdd(st + tid, (double)a);
       atomicAdd(st + p.cout + tid, (double)b);
