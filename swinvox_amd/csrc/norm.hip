@@ -432,44 +432,50 @@ template <typename AT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const AT* __restrict__ dz, int lddz, const AT* __restrict__ z, int ldz,
                                                             const AT* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, long long M, int C, int act, float slope,
-                                                            double* __restrict__ sums, long long rows_per_block,
+                                                            double* __restrict__ sums, long long rows_per_block, int CW,
                                                             const float* __restrict__ fsc, const float* __restrict__ fsh) {
-  __shared__ double r1[4][64], r2[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  // CW (a power of two <= 64) lanes across the channels, 256 / CW row lanes: with one or two channels every thread still works
+  __shared__ double r1[256], r2[256];
+  const int cl = threadIdx.x & (CW - 1), c = blockIdx.x * CW + cl, rl = threadIdx.x / CW, RL = 256 / CW;
   const long long r0 = (long long)blockIdx.y * rows_per_block;
   long long r1e = r0 + rows_per_block; if (r1e > M) r1e = M;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     const float mu = mean[c], rs = rstd[c];
     const float msc = z ? 0.f : fsc[c], msh = z ? 0.f : fsh[c];     // no saved output: the mask is recomputed from x
+    const float neg = act == SV_ACT_LRELU ? slope : 0.f;
     long long r = r0 + rl;
-    for (; r + 12 < r1e; r += 16) {   // 4 rows in flight per thread (independent loads), then the serial tail
+    for (; r + 3 * RL < r1e; r += 4 * RL) {   // 4 rows in flight per thread (independent loads), then the serial tail
       float d[4], xv[4], zv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        d[u] = ldf(dz + (size_t)(r + 4 * u) * lddz + c);
-        xv[u] = ldf(x + (size_t)(r + 4 * u) * ldx + c);
-        zv[u] = act != SV_ACT_NONE ? (z ? ldf(z + (size_t)(r + 4 * u) * ldz + c) : __fmaf_rn(xv[u], msc, msh)) : 1.f;
+        d[u] = ldf(dz + (size_t)(r + RL * u) * lddz + c);
+        xv[u] = ldf(x + (size_t)(r + RL * u) * ldx + c);
+        zv[u] = act != SV_ACT_NONE ? (z ? ldf(z + (size_t)(r + RL * u) * ldz + c) : __fmaf_rn(xv[u], msc, msh)) : 1.f;
       }
+      float f1 = 0.f, f2 = 0.f;               // four rows in fp32, then into the double accumulators
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (act != SV_ACT_NONE) d[u] *= (zv[u] > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
-        s1 += (double)d[u]; s2 += (double)(d[u] * (xv[u] - mu) * rs);
+        if (act != SV_ACT_NONE) d[u] *= (zv[u] > 0.f) ? 1.f : neg;
+        f1 += d[u]; f2 += d[u] * (xv[u] - mu) * rs;
       }
+      s1 += (double)f1; s2 += (double)f2;
     }
-    for (; r < r1e; r += 4) {
+    for (; r < r1e; r += RL) {
       float d = ldf(dz + (size_t)r * lddz + c);
       const float xq = ldf(x + (size_t)r * ldx + c);
-      if (act != SV_ACT_NONE) d *= ((z ? ldf(z + (size_t)r * ldz + c) : __fmaf_rn(xq, msc, msh)) > 0.f) ? 1.f : (act == SV_ACT_LRELU ? slope : 0.f);
+      if (act != SV_ACT_NONE) d *= ((z ? ldf(z + (size_t)r * ldz + c) : __fmaf_rn(xq, msc, msh)) > 0.f) ? 1.f : neg;
       s1 += (double)d; s2 += (double)(d * (xq - mu) * rs);
     }
   }
-  r1[rl][threadIdx.x & 63] = s1; r2[rl][threadIdx.x & 63] = s2;
+  r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
   __syncthreads();
   if (rl == 0 && c < C) {
+    double a = 0.0, b = 0.0;
+    for (int l = 0; l < RL; ++l) { a += r1[l * CW + cl]; b += r2[l * CW + cl]; }
     double* slot = sums + (size_t)(blockIdx.y % BN_BWD_SLOTS) * 2 * C;
-    atomicAdd(slot + c, r1[0][threadIdx.x] + r1[1][threadIdx.x] + r1[2][threadIdx.x] + r1[3][threadIdx.x]);
-    atomicAdd(slot + C + c, r2[0][threadIdx.x] + r2[1][threadIdx.x] + r2[2][threadIdx.x] + r2[3][threadIdx.x]);
+    atomicAdd(slot + c, a);
+    atomicAdd(slot + C + c, b);
   }
 }
 
@@ -1000,11 +1006,12 @@ extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const
       hipLaunchKernelGGL(bn_bwd_apply_cg_kernel<AT>, dim3(cg, cdiv(M, arpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
                          act, slope, training, dx_, lddx, dres_, lddres, fsc, fsh, arpb, G);
     } else {
-      const int cg = cdiv(C, 64);
+      int CW = 1; while (CW < C && CW < 64) CW <<= 1;         // channel lanes: next power of two of C, at most 64
+      const int cg = cdiv(C, CW), RLg = 256 / CW;
       long long splits = 2048 / cg; if (splits < 1) splits = 1;
-      const long long maxs = (M + 63) / 64; if (splits > maxs) splits = maxs;
+      const long long maxs = (M + 4 * RLg - 1) / (4 * RLg); if (splits > maxs) splits = maxs;
       const long long rpb = (M + splits - 1) / splits;
-      hipLaunchKernelGGL(bn_bwd_reduce_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope, sums_ws, rpb, fsc, fsh);
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope, sums_ws, rpb, CW, fsc, fsh);
       hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);
       long long blocks = (M * C + 255) / 256; if (blocks > 8192) blocks = 8192;
       hipLaunchKernelGGL(bn_bwd_apply_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
