@@ -121,7 +121,11 @@ class Merger(HipModule):
         # activations where layer 5 reads them.  Stencil back-end: four DENSE planes [4][M][12] (every per-layer pass streams
         # whole cache lines); generic fp32 engine: 12-column windows of 48-wide rows (one 48-channel input).
         planar = ops.get_math() == "bf16"
-        cat = zeros(4, M, 12, like=vol) if planar else zeros(M, 48, like=vol)
+        # stencil back-end: every 12-wide row is written whole by its producer (9 channels + 3 zero pads: sv_stencil3_fwd and the
+        # narrow BatchNorm kernels store complete 4-channel groups), so these buffers need no zero fill; the generic engine of the
+        # fp32 mode writes the 9 real columns only
+        buf = empty if planar else zeros
+        cat = empty(4, M, 12, like=vol) if planar else zeros(M, 48, like=vol)
         ldz = 12 if planar else 48
         w5p = self._w5_padded() if not planar else None
         ctx14, xin, ldi = [], x12, 12
@@ -139,7 +143,7 @@ class Merger(HipModule):
         st5 = BatchNormState(self.layer5[1], M, tr)
         self._conv_fwd(4, cat, ldz, y5, 12, st5.sums, w5p)
         st5.finalize()
-        z5 = zeros(M, 12, like=vol)
+        z5 = buf(M, 12, like=vol)
         st5.apply(y5, 12, z5, 12, ACT_LRELU, sl)
         y6 = empty(M, 1, like=vol)
         st6 = BatchNormState(self.layer6[1], M, tr)
@@ -165,18 +169,19 @@ class Merger(HipModule):
         st6.backward(dwl, 1, wl, 1, y6, 1, dy6, 4, grads[bn6.weight], grads[bn6.bias], ACT_LRELU, sl)
         self._bias_grad(dy6, M, 1, 4, grads[conv6.bias])
         self._conv_wgrad(5, dy6, 4, z5, 12, grads)
-        dz5 = zeros(M, 12, like=vol)
+        buf = empty if ops.get_math() == "bf16" else zeros   # see _fwd: whole rows are written by the stencil / narrow kernels
+        dz5 = buf(M, 12, like=vol)
         self._conv_dgrad(5, dy6, 4, dz5, 12, False)
         # ---- layer 5
         conv5, bn5 = self.layer5[0], self.layer5[1]
-        dy5 = zeros(M, 12, like=vol)
+        dy5 = buf(M, 12, like=vol)
         st5.backward(dz5, 12, z5, 12, y5, 12, dy5, 12, grads[bn5.weight], grads[bn5.bias], ACT_LRELU, sl)
         self._bias_grad(dy5, M, 9, 12, grads[conv5.bias])
         planar = cat.dim() == 3
         ldz = 12 if planar else 48
         self._conv_wgrad(4, dy5, 12, cat, ldz, grads)
         # data-gradient wrt the concat buffer, same storage scheme as `cat` (pad columns receive zero weights)
-        dcat = zeros(4, M, 12, like=vol) if planar else zeros(M, 48, like=vol)
+        dcat = empty(4, M, 12, like=vol) if planar else zeros(M, 48, like=vol)
         self._conv_dgrad(4, dy5, 12, dcat, ldz, False, w5p)
         # ---- layers 4..1: z_k feeds layer k+1 and the concat -> gradients add up in dcat[:, 12k:12k+9]
         dx = None
@@ -184,14 +189,14 @@ class Merger(HipModule):
             conv, bn = self._layer(k)[0], self._layer(k)[1]
             xin, ldi, y, z, st = ctx14[k]
             dzk = dcat[k] if planar else dcat[:, 12 * k:]
-            dy = zeros(M, 12, like=vol)
+            dy = buf(M, 12, like=vol)
             st.backward(dzk, ldz, z, ldz, y, 12, dy, 12, grads[bn.weight], grads[bn.bias], ACT_LRELU, sl)
             self._bias_grad(dy, M, 9, 12, grads[conv.bias])
             self._conv_wgrad(k, dy, 12, xin, ldi, grads)
             if k > 0:   # accumulate into the previous layer's slot of dcat
                 self._conv_dgrad(k, dy, 12, dcat[k - 1] if planar else dcat[:, 12 * (k - 1):], ldz, True)
             else:
-                dx = zeros(M, 12, like=vol)
+                dx = buf(M, 12, like=vol)
                 self._conv_dgrad(k, dy, 12, dx, 12, False)
         draw = raw_view(ops.to_f32(dx), B, V) if in_needs[0] else None
         return (draw, ops.to_f32(dvol) if in_needs[1] else None)

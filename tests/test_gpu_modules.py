@@ -294,3 +294,30 @@ def test_bf16_math(dev, nets, storage):
             if float(b.grad.abs().max()) > 1e-8:
                 l1 = float((a.grad.cpu() - b.grad).abs().sum() / b.grad.abs().sum())
                 assert l1 < 0.3, (type(p).__name__, k, l1)
+
+
+def test_merger_reads_no_uninitialised_memory(dev):
+    """The stencil back-end of the merger allocates its padded 12-wide buffers without zero fill (every row is written whole by
+    its producer).  Poison the allocator's free memory with NaN first: any pad column that is read before it is written would
+    turn the output / the gradients into NaN."""
+    import swinvox_amd as S
+    from swinvox_amd.models import Merger
+    m = Merger(S.default_cfg()).to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    raw = torch.randn(2, 3, 9, 32, 32, 32, generator=g).to(dev).requires_grad_(True)
+    vol = torch.randn(2, 3, 32, 32, 32, generator=g).to(dev).requires_grad_(True)
+    S.set_math("bf16")
+    S.set_storage("bf16")
+    try:
+        for _ in range(2):
+            torch.cuda.empty_cache()
+            poison = [torch.full((64 << 20,), float("nan"), dtype=torch.bfloat16, device=dev) for _ in range(6)]   # 768 MB of NaN
+            del poison                                   # back to the caching allocator, contents intact
+            m.zero_grad(set_to_none=True)
+            raw.grad = vol.grad = None
+            out = m(raw, vol)
+            out.sum().backward()
+            assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(raw.grad).all()) and bool(torch.isfinite(vol.grad).all())
+            assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    finally:
+        S.set_math("f32")
