@@ -166,7 +166,9 @@ class Merger(HipModule):
         # ---- layer 6
         conv6, bn6 = self.layer6[0], self.layer6[1]
         dy6 = zeros(M, 4, like=vol)
-        st6.backward(dwl, 1, wl, 1, y6, 1, dy6, 4, grads[bn6.weight], grads[bn6.bias], ACT_LRELU, sl)
+        # z = None everywhere below: the LeakyReLU mask is recomputed from the conv output (scale * y + shift > 0), one tensor read
+        # less in each of the two BatchNorm backward passes
+        st6.backward(dwl, 1, None, 0, y6, 1, dy6, 4, grads[bn6.weight], grads[bn6.bias], ACT_LRELU, sl)
         self._bias_grad(dy6, M, 1, 4, grads[conv6.bias])
         self._conv_wgrad(5, dy6, 4, z5, 12, grads)
         buf = empty if ops.get_math() == "bf16" else zeros   # see _fwd: whole rows are written by the stencil / narrow kernels
@@ -175,7 +177,7 @@ class Merger(HipModule):
         # ---- layer 5
         conv5, bn5 = self.layer5[0], self.layer5[1]
         dy5 = buf(M, 12, like=vol)
-        st5.backward(dz5, 12, z5, 12, y5, 12, dy5, 12, grads[bn5.weight], grads[bn5.bias], ACT_LRELU, sl)
+        st5.backward(dz5, 12, None, 0, y5, 12, dy5, 12, grads[bn5.weight], grads[bn5.bias], ACT_LRELU, sl)
         self._bias_grad(dy5, M, 9, 12, grads[conv5.bias])
         planar = cat.dim() == 3
         ldz = 12 if planar else 48
@@ -190,7 +192,7 @@ class Merger(HipModule):
             xin, ldi, y, z, st = ctx14[k]
             dzk = dcat[k] if planar else dcat[:, 12 * k:]
             dy = buf(M, 12, like=vol)
-            st.backward(dzk, ldz, z, ldz, y, 12, dy, 12, grads[bn.weight], grads[bn.bias], ACT_LRELU, sl)
+            st.backward(dzk, ldz, None, 0, y, 12, dy, 12, grads[bn.weight], grads[bn.bias], ACT_LRELU, sl)
             self._bias_grad(dy, M, 9, 12, grads[conv.bias])
             self._conv_wgrad(k, dy, 12, xin, ldi, grads)
             if k > 0:   # accumulate into the previous layer's slot of dcat
