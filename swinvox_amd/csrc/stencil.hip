@@ -92,7 +92,7 @@ struct StencilArgsT {                         // AT = storage element of the act
 };
 
 template <int G, int NT, typename AT>
-__global__ __launch_bounds__(256) void stencil3_fwd_kernel(const StencilArgsT<AT> p) {
+__global__ __launch_bounds__(256, G == 1 && NT == 1 ? 4 : 1) void stencil3_fwd_kernel(const StencilArgsT<AT> p) {
   constexpr int C = 16 * G, KTOT = 27 * C, KPAD = (KTOT + 31) / 32 * 32, NSTEP = KPAD / 32;
   __shared__ __attribute__((aligned(16))) char xc[HPOS * C * 2];   // halo brick
   __shared__ __attribute__((aligned(16))) __bf16 Ws[NT * 16 * KPAD];
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void stencil_wgrad_fold_kernel(const float* __
 }
 
 template <int G, typename AT>
-__global__ __launch_bounds__(256) void stencil3_wgrad_kernel(const StencilWArgsT<AT> p) {
+__global__ __launch_bounds__(256, G == 1 ? 3 : 1) void stencil3_wgrad_kernel(const StencilWArgsT<AT> p) {
   constexpr int C = 16 * G;
   __shared__ __attribute__((aligned(16))) __bf16 Xs[HPOS * C];
   __shared__ __attribute__((aligned(16))) __bf16 Ds[NVOX * 16];
