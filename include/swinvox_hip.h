@@ -163,8 +163,9 @@ int sv_bn_finalize(const double* sums, long long count, const float* gamma, cons
                    float* running_var, float momentum, float eps, int training, float* scale, float* shift,
                    float* save_mean, float* save_rstd, int C, void* stream);
 /* Padded rows: when C is not a multiple of 4, C <= 16 and every row stride involved is a multiple of 4 elements and
- * >= roundup4(C), sv_scale_shift_act and sv_bn_bwd treat the columns C .. roundup4(C)-1 as PADDING of the row: they read them
- * (finite values required) and write ZERO there (y / dx / dres are stored as whole 4-channel vectors).  A 9-channel tensor kept
+ * >= roundup4(C), sv_scale_shift_act and sv_bn_bwd treat the columns C .. roundup4(C)-1 as PADDING of the row: whatever they
+ * hold on input is ignored (it may be uninitialised memory) and ZERO is written there (y / dx / dres are stored as whole
+ * 4-channel vectors).  A 9-channel tensor kept
  * in 12-wide rows therefore never needs a separate zero fill (swinvox_amd/models/merger.py relies on this). */
 int sv_scale_shift_act(const void* x, int ldx, const float* scale, const float* shift, const void* residual, int ldr,
                        void* y, int ldy, long long M, int C, int act, float slope, int act_dtype, void* stream);

@@ -638,10 +638,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_narrow_kernel(const AT* __re
 #pragma unroll
       for (int j = 0; j < 4; ++j) d[j] *= zz[j] > 0.f ? 1.f : neg;
     }
-    if (dres) st4f(dres + (size_t)r * lddres + 4 * g, make_float4(d[0], d[1], d[2], d[3]));
     float o[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (float)(k1[j] * (double)d[j] - k2[j] - k3[j] * (double)xx[j]);
+    for (int j = 0; j < 4; ++j) {   // padding columns: whatever was read (possibly uninitialised memory) is ignored, zero is written
+      const bool real = 4 * g + j < C;
+      o[j] = real ? (float)(k1[j] * (double)d[j] - k2[j] - k3[j] * (double)xx[j]) : 0.f;
+      if (!real) d[j] = 0.f;
+    }
+    if (dres) st4f(dres + (size_t)r * lddres + 4 * g, make_float4(d[0], d[1], d[2], d[3]));
     st4f(dx + (size_t)r * lddx + 4 * g, make_float4(o[0], o[1], o[2], o[3]));
   }
 }

@@ -296,28 +296,42 @@ def test_bf16_math(dev, nets, storage):
                 assert l1 < 0.3, (type(p).__name__, k, l1)
 
 
-def test_merger_reads_no_uninitialised_memory(dev):
-    """The stencil back-end of the merger allocates its padded 12-wide buffers without zero fill (every row is written whole by
-    its producer).  Poison the allocator's free memory with NaN first: any pad column that is read before it is written would
-    turn the output / the gradients into NaN."""
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("which", ["encoder", "decoder", "merger", "refiner"])
+def test_modules_read_no_uninitialised_memory(dev, which, mode):
+    """Buffers are allocated with torch.empty wherever their producer writes every element that is read later (padded rows are
+    written whole, or their padding is ignored).  Poison the allocator's free memory with NaN first: a read of memory nobody
+    wrote turns the outputs / the gradients into NaN (found one in the fp32 path of the merger when this test was added)."""
     import swinvox_amd as S
-    from swinvox_amd.models import Merger
-    m = Merger(S.default_cfg()).to(dev).train()
+    from swinvox_amd.models import Decoder, Encoder, Merger, Refiner
+    cfg = S.default_cfg()
     g = torch.Generator().manual_seed(5)
-    raw = torch.randn(2, 3, 9, 32, 32, 32, generator=g).to(dev).requires_grad_(True)
-    vol = torch.randn(2, 3, 32, 32, 32, generator=g).to(dev).requires_grad_(True)
-    S.set_math("bf16")
-    S.set_storage("bf16")
+    rnd = lambda *sh: torch.randn(*sh, generator=g).to(dev).requires_grad_(True)
+    if which == "encoder":
+        m, ins = Encoder(cfg), [rnd(1, 2, 3, 224, 224)]
+    elif which == "decoder":
+        m, ins = Decoder(cfg), [rnd(2, 3, 256, 7, 7)]
+    elif which == "merger":
+        m, ins = Merger(cfg), [rnd(2, 3, 9, 32, 32, 32), rnd(2, 3, 32, 32, 32)]
+    else:
+        m, ins = Refiner(cfg), [rnd(3, 32, 32, 32)]
+    m = m.to(dev).train()
+    S.set_math(mode)
+    if mode == "bf16":
+        S.set_storage("bf16")
     try:
         for _ in range(2):
             torch.cuda.empty_cache()
-            poison = [torch.full((64 << 20,), float("nan"), dtype=torch.bfloat16, device=dev) for _ in range(6)]   # 768 MB of NaN
+            poison = [torch.full((64 << 20,), float("nan"), dtype=torch.bfloat16, device=dev) for _ in range(8)]   # 1 GB of NaN
             del poison                                   # back to the caching allocator, contents intact
             m.zero_grad(set_to_none=True)
-            raw.grad = vol.grad = None
-            out = m(raw, vol)
-            out.sum().backward()
-            assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(raw.grad).all()) and bool(torch.isfinite(vol.grad).all())
+            for t in ins:
+                t.grad = None
+            out = m(*ins)
+            outs = [out] if isinstance(out, torch.Tensor) else list(out)
+            sum(o.sum() for o in outs).backward()
+            assert all(bool(torch.isfinite(o).all()) for o in outs)
+            assert all(bool(torch.isfinite(t.grad).all()) for t in ins if t.grad is not None)
             assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
     finally:
         S.set_math("f32")
