@@ -10,7 +10,8 @@
 //       [position][channel] images through ds_read_b64_tr_b16; the four waves split the 27 taps.
 // Both kernels are PERSISTENT over bricks: weights / partial sums are set up once per workgroup, and the next brick's
 // halo is prefetched into registers while the current one is contracted (global latency hidden behind the MFMA loop).
-// The forward epilogue stages the tile in LDS and stores whole channel rows per voxel (8-byte vectors).
+// The forward accumulators are transposed blocks (weight fragment as the MFMA's first operand): a lane holds four consecutive
+// channels of one voxel and stores them straight from its registers (8-byte vectors); per-channel statistics stay in registers.
 // bf16 operands, fp32 accumulate (these kernels serve set_math("bf16"); exact-fp32 parity runs use the generic engine).
 #include "common.h"
 #include <map>
