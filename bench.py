@@ -95,25 +95,26 @@ def main():
     from swinvox_amd import hip
     from swinvox_amd.dp import GradAllReducer
     from swinvox_amd.models import Decoder, Encoder, Merger, Refiner
-    import oracle as O   # only for init_weights-equivalent recipe below and the cpu_baseline leg
+    from swinvox_amd.helpers import init_weights
+    from swinvox_amd.losses import bce_with_logits as bce
 
     hip.load()
     S.set_math(args.math)
     S.set_storage(args.storage if args.math == "bf16" else "f32")
     S.set_overlap(not args.no_overlap)
-    torch.manual_seed(1234 + rank)
+    torch.manual_seed(1234)              # the SAME weights on every rank (the reducer also broadcasts rank 0's at construction)
     cfg = S.default_cfg()
     nets = [Encoder(cfg), Decoder(cfg), Merger(cfg), Refiner(cfg)]
     for n in nets:
-        n.apply(O.init_weights)          # reference weight recipe (utils/helpers.py:20-44); values do not affect speed
+        n.apply(init_weights)            # reference weight recipe (utils/helpers.py:20-44); values do not affect speed
         n.to(dev).train()
+    torch.manual_seed(4321 + rank)       # per-rank stream for dropout / drop-path seeds
     reducer = GradAllReducer([nets[3], nets[2], nets[1], nets[0]]) if world > 1 else None
 
     B, V = args.batch, args.views
     g = torch.Generator().manual_seed(rank)
     images = (0.5 * torch.randn(B, V, 3, 224, 224, generator=g)).clamp(-1, 1).to(dev)
     gt = (torch.rand(B, 32, 32, 32, generator=g) < 0.10).float().to(dev)
-    bce = torch.nn.functional.binary_cross_entropy_with_logits
 
     def step():
         for n in nets:

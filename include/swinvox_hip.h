@@ -237,12 +237,16 @@ int sv_iou_counts(const float* logits, const float* gt, const float* thresholds_
  *  sv_adam_step / sv_sgd_step: torch.optim.Adam (coupled L2 weight decay, no amsgrad) / torch.optim.SGD (momentum) as
  *    configured at core/train.py:98-131 and stepped at :287-292.  Every gradient is first multiplied by
  *    gscale * min(1, max_norm / (sqrt(sum slots16) + 1e-6)) - the data-parallel mean and the clip coefficient, read on the
- *    device; slots16 == NULL or max_norm <= 0 disables clipping.  `step` counts from 1 (bias correction).            */
+ *    device; max_norm <= 0 disables clipping.  `step` counts the calls from 1.  When slots16 is given and its sum is not
+ *    finite (an inf / NaN gradient element) the step is SKIPPED on the device: p, m, v stay untouched and
+ *    skipped_steps[0] (device counter, may be NULL) += 1 - the behaviour of the reference's GradScaler.step() after
+ *    unscale_ (core/train.py:276-293).  Bias correction / "first step" use step - skipped_steps[0].                  */
 int sv_grad_sumsq(const float* g, long long n, float gscale, double* slots16, void* stream);
 int sv_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
-                 double weight_decay, long long step, float gscale, const double* slots16, float max_norm, void* stream);
+                 double weight_decay, long long step, float gscale, const double* slots16, float max_norm,
+                 long long* skipped_steps, void* stream);
 int sv_sgd_step(float* p, const float* g, float* momentum_buf, long long n, double lr, double momentum, double weight_decay,
-                int first_step, float gscale, const double* slots16, float max_norm, void* stream);
+                long long step, float gscale, const double* slots16, float max_norm, long long* skipped_steps, void* stream);
 
 /* Input preparation on the device (the reference does it per sample on the CPU in DataLoader workers).
  *  sv_binvox_decode: utils/binvox_rw.py:118-149 (read_as_3d_array) for B volumes of equal dims: `rle` holds the concatenated

@@ -92,14 +92,16 @@ def resize_linear(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
 
 
 # ---- transforms ------------------------------------------------------------------------------------------------------------------
-def draw_train_params(n_views: int, cfg_train: Dict, rng_np=np.random, rng_py=random) -> Dict:
+def draw_train_params(n_views: int, cfg_train: Dict, rng_np=np.random, rng_py=random, n_channels: int = 4) -> Dict:
     """Random draws of one __getitem__ in the reference's call order (data_transforms.py): RandomBackground (:425-428 three
     randint, then one random.randint per image at :440), ColorJitter (:276-284), RandomNoise (:372), RandomFlip (:252-255),
     RandomPermuteRGB (:67)."""
     rg = cfg_train["RANDOM_BG_COLOR_RANGE"]
-    bg = np.array([rng_np.randint(rg[i][0], rg[i][1] + 1) for i in range(3)]) / 255.0
-    for _ in range(n_views):
-        rng_py.randint(0, 1)                                              # drawn although no background folder is configured
+    bg = np.ones(3)
+    if n_channels == 4:                                                   # :428-430: RGB renderings return before any draw
+        bg = np.array([rng_np.randint(rg[i][0], rg[i][1] + 1) for i in range(3)]) / 255.0
+        for _ in range(n_views):
+            rng_py.randint(0, 1)                                          # drawn although no background folder is configured
     brightness = 1 + rng_np.uniform(low=-cfg_train["BRIGHTNESS"], high=cfg_train["BRIGHTNESS"])
     contrast = 1 + rng_np.uniform(low=-cfg_train["CONTRAST"], high=cfg_train["CONTRAST"])
     saturation = 1 + rng_np.uniform(low=-cfg_train["SATURATION"], high=cfg_train["SATURATION"])

@@ -249,7 +249,8 @@ class SwinBackbone(nn.Module):
             dim = embed_dim * 2 ** i
             if i > 0:
                 res //= 2
-            setattr(self, f"layers_{i}", SwinStage(dim_in, dim, res, d, heads[i], window, dps[ofs:ofs + d], i > 0))
+            if i <= max(self.out_indices):   # timm FeatureListNet (timm/models/_features.py) prunes the modules after the last out index
+                setattr(self, f"layers_{i}", SwinStage(dim_in, dim, res, d, heads[i], window, dps[ofs:ofs + d], i > 0))
             ofs += d
             dim_in = dim
             chans.append(dim)

@@ -33,17 +33,36 @@ __global__ void __launch_bounds__(256) grad_sumsq_kernel(const float* __restrict
 
 // gradient multiplier of the step: gscale (1/world of the data-parallel mean) x the clip_grad_norm_ coefficient
 // min(1, max_norm / (||g|| + 1e-6)) (torch.nn.utils.clip_grad_norm_, reference core/train.py:279-282)
-__device__ __forceinline__ float grad_multiplier(const double* slots, float gscale, float max_norm) {
-  if (slots == nullptr || max_norm <= 0.f) return gscale;
+// `finite` = the squared norm is finite, i.e. no gradient element is inf / NaN.  A non-finite gradient SKIPS the step
+// (parameters, moments and the effective step count stay untouched) - what torch.amp.GradScaler.step() does in the
+// reference after unscale_ found an inf (core/train.py:276-293) - instead of poisoning p / m / v with NaN for good.
+__device__ __forceinline__ float grad_multiplier(const double* slots, float gscale, float max_norm, bool& finite) {
+  finite = true;
+  if (slots == nullptr) return gscale;
   double s = 0.0;
 #pragma unroll
   for (int i = 0; i < OPT_SLOTS; ++i) s += slots[i];
+  finite = isfinite(s);
+  if (max_norm <= 0.f) return gscale;
   const float coef = max_norm / ((float)sqrt(s) + 1e-6f);
   return gscale * fminf(coef, 1.f);
 }
 
+// steps that really happened = host step count - device count of skipped steps (read before block 0 may bump it: every
+// block of a skipped step returns without reading it, every block of a taken step only reads it)
+__device__ __forceinline__ long long effective_step(long long step, long long* skipped, bool finite) {
+  if (!finite) {
+    if (skipped != nullptr && blockIdx.x == 0 && threadIdx.x == 0) skipped[0] += 1;
+    return 0;
+  }
+  return step - (skipped != nullptr ? skipped[0] : 0);
+}
+
 struct AdamArgs {
-  float step_size, beta1, beta2, eps, weight_decay, bc2_sqrt, gscale, max_norm;
+  float lr, beta1, beta2, eps, weight_decay, gscale, max_norm;
+  double dbeta1, dbeta2, dlr;
+  long long step;
+  float step_size, bc2_sqrt;   // filled on the device from the effective step
 };
 
 // torch.optim.Adam (coupled L2 weight decay, no amsgrad), the operation order of torch/optim/adam.py::_single_tensor_adam
@@ -58,8 +77,14 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 
 __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                        float* __restrict__ v, long long n, AdamArgs a, const double* __restrict__ slots) {
-  const float gm = grad_multiplier(slots, a.gscale, a.max_norm);
+                                                        float* __restrict__ v, long long n, AdamArgs a, const double* __restrict__ slots,
+                                                        long long* __restrict__ skipped) {
+  bool finite;
+  const float gm = grad_multiplier(slots, a.gscale, a.max_norm, finite);
+  const long long t = effective_step(a.step, skipped, finite);
+  if (!finite) return;
+  a.step_size = (float)(a.dlr / (1.0 - pow(a.dbeta1, (double)t)));        // lr / bias_correction1
+  a.bc2_sqrt = (float)sqrt(1.0 - pow(a.dbeta2, (double)t));
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -83,7 +108,8 @@ __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, c
 
 struct SgdArgs {
   float lr, momentum, weight_decay, gscale, max_norm;
-  int first;
+  long long step;
+  int first;                   // filled on the device: the effective step is the first one
 };
 
 // torch.optim.SGD (momentum, dampening 0, no nesterov): buf = g (first step) or momentum * buf + g; p -= lr * buf
@@ -95,8 +121,12 @@ __device__ __forceinline__ void sgd_one(float& p, float g, float& b, const SgdAr
 }
 
 __global__ void __launch_bounds__(256) sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long long n,
-                                                       SgdArgs a, const double* __restrict__ slots) {
-  const float gm = grad_multiplier(slots, a.gscale, a.max_norm);
+                                                       SgdArgs a, const double* __restrict__ slots, long long* __restrict__ skipped) {
+  bool finite;
+  const float gm = grad_multiplier(slots, a.gscale, a.max_norm, finite);
+  const long long t = effective_step(a.step, skipped, finite);
+  if (!finite) return;
+  a.first = t == 1 ? 1 : 0;
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -135,27 +165,32 @@ extern "C" int sv_grad_sumsq(const float* g, long long n, float gscale, double* 
 }
 
 extern "C" int sv_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
-                            double weight_decay, long long step, float gscale, const double* slots16, float max_norm, void* stream) {
+                            double weight_decay, long long step, float gscale, const double* slots16, float max_norm,
+                            long long* skipped_steps, void* stream) {
   SV_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
   SV_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adam_step: buffers must be 16-byte aligned");
   SV_REQUIRE(beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0, "adam_step: bad hyper-parameters");
-  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   AdamArgs a;
-  a.step_size = (float)(lr / bc1);
+  a.lr = (float)lr;
+  a.dlr = lr;
+  a.dbeta1 = beta1;
+  a.dbeta2 = beta2;
+  a.step = step;
   a.beta1 = (float)beta1;
   a.beta2 = (float)beta2;
   a.eps = (float)eps;
   a.weight_decay = (float)weight_decay;
-  a.bc2_sqrt = (float)sqrt(bc2);
   a.gscale = gscale;
   a.max_norm = max_norm;
-  hipLaunchKernelGGL(adam_step_kernel, dim3(stream_grid(n)), dim3(256), 0, STREAM, p, g, m, v, n, a, slots16);
+  a.step_size = 0.f;
+  a.bc2_sqrt = 1.f;
+  hipLaunchKernelGGL(adam_step_kernel, dim3(stream_grid(n)), dim3(256), 0, STREAM, p, g, m, v, n, a, slots16, skipped_steps);
   return check_launch("sv_adam_step");
 }
 
-extern "C" int sv_sgd_step(float* p, const float* g, float* buf, long long n, double lr, double momentum, double weight_decay, int first_step,
-                           float gscale, const double* slots16, float max_norm, void* stream) {
-  SV_REQUIRE(p && g && buf && n > 0, "sgd_step: bad arguments");
+extern "C" int sv_sgd_step(float* p, const float* g, float* buf, long long n, double lr, double momentum, double weight_decay, long long step,
+                           float gscale, const double* slots16, float max_norm, long long* skipped_steps, void* stream) {
+  SV_REQUIRE(p && g && buf && n > 0 && step >= 1, "sgd_step: bad arguments");
   SV_REQUIRE(aligned16(p) && aligned16(g) && aligned16(buf), "sgd_step: buffers must be 16-byte aligned");
   SgdArgs a;
   a.lr = (float)lr;
@@ -163,7 +198,8 @@ extern "C" int sv_sgd_step(float* p, const float* g, float* buf, long long n, do
   a.weight_decay = (float)weight_decay;
   a.gscale = gscale;
   a.max_norm = max_norm;
-  a.first = first_step ? 1 : 0;
-  hipLaunchKernelGGL(sgd_step_kernel, dim3(stream_grid(n)), dim3(256), 0, STREAM, p, g, buf, n, a, slots16);
+  a.step = step;
+  a.first = 0;
+  hipLaunchKernelGGL(sgd_step_kernel, dim3(stream_grid(n)), dim3(256), 0, STREAM, p, g, buf, n, a, slots16, skipped_steps);
   return check_launch("sv_sgd_step");
 }

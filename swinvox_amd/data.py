@@ -91,15 +91,19 @@ class AugParams:
         return np.sum(np.multiply(np.multiply(np.array(EIGVECS), np.tile(a, (3, 1))), np.tile(np.array(EIGVALS), (3, 1))), axis=1)
 
 
-def draw_train_params(n_views: int, cfg, rng_np=np.random, rng_py=random) -> AugParams:
+def draw_train_params(n_views: int, cfg, rng_np=np.random, rng_py=random, n_channels: int = 4) -> AugParams:
     """One __getitem__ worth of random draws in the reference's call order: RandomBackground (data_transforms.py:425-428, plus
     the per-image random.randint of :440), ColorJitter (:276-284), RandomNoise (:372), RandomFlip (:252-255),
-    RandomPermuteRGB (:67).  RandomCrop draws nothing without a bounding box (:222-231)."""
+    RandomPermuteRGB (:67).  RandomCrop draws nothing without a bounding box (:222-231).  RandomBackground returns before it draws
+    anything when the renderings have no alpha channel (:428-430): pass n_channels=3 for RGB inputs."""
     t = cfg.TRAIN
     rg = t.RANDOM_BG_COLOR_RANGE
-    bg = np.array([rng_np.randint(rg[i][0], rg[i][1] + 1) for i in range(3)]) / 255.0
-    for _ in range(n_views):
-        rng_py.randint(0, 1)
+    if n_channels == 4:
+        bg = np.array([rng_np.randint(rg[i][0], rg[i][1] + 1) for i in range(3)]) / 255.0
+        for _ in range(n_views):
+            rng_py.randint(0, 1)
+    else:
+        bg = np.ones(3)                       # unused: the composite step is skipped for 3-channel images
     jv = [1 + rng_np.uniform(low=-t.BRIGHTNESS, high=t.BRIGHTNESS), 1 + rng_np.uniform(low=-t.CONTRAST, high=t.CONTRAST),
           1 + rng_np.uniform(low=-t.SATURATION, high=t.SATURATION)]
     order = np.array(range(3))
@@ -111,10 +115,10 @@ def draw_train_params(n_views: int, cfg, rng_np=np.random, rng_py=random) -> Aug
                      perm=[int(i) for i in perm])
 
 
-def val_params(n_views: int, cfg) -> AugParams:
-    """core/train.py:60-65: CenterCrop, RandomBackground(cfg.TEST.RANDOM_BG_COLOR_RANGE), Normalize, ToTensor."""
+def val_params(n_views: int, cfg, n_channels: int = 4) -> AugParams:
+    """core/train.py:60-65: CenterCrop, RandomBackground(cfg.TEST.RANDOM_BG_COLOR_RANGE), Normalize, ToTensor (no draws for RGB inputs)."""
     rg = cfg.TEST.RANDOM_BG_COLOR_RANGE
-    bg = np.array([np.random.randint(rg[i][0], rg[i][1] + 1) for i in range(3)]) / 255.0
+    bg = np.array([np.random.randint(rg[i][0], rg[i][1] + 1) for i in range(3)]) / 255.0 if n_channels == 4 else np.ones(3)
     return AugParams(bg=bg.tolist(), flips=[False] * n_views)
 
 

@@ -17,10 +17,26 @@ from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 from .optim import flat_region
 
 
+def sync_module_states(modules: Sequence[torch.nn.Module], group=None, src: int = 0) -> int:
+    """Every parameter and buffer (BatchNorm running statistics, num_batches_tracked) of `modules` := rank `src`'s, in
+    coalesced broadcasts - what DataParallel's replicate() does every step (core/train.py:156-161) and DDP does once at
+    construction.  Without it ranks that seeded or loaded differently would average gradients of different models.
+    In-place copies: parameters that are views of a flat solver buffer stay views.  Returns the number of tensors synced."""
+    tensors = []
+    for m in modules:
+        tensors += [p.data for p in m.parameters()] + [b.data for b in m.buffers()]
+    if tensors and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        pg = group if group is not None else dist.group.WORLD
+        dist._broadcast_coalesced(pg, tensors, 256 << 20, src)
+    return len(tensors)
+
+
 class GradAllReducer:
-    def __init__(self, modules: Sequence[torch.nn.Module], bucket_bytes: int = 64 << 20, group=None):
+    def __init__(self, modules: Sequence[torch.nn.Module], bucket_bytes: int = 64 << 20, group=None, sync_states: bool = True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if sync_states and self.world > 1:
+            sync_module_states(modules, group)
         self.buckets: List[List[torch.nn.Parameter]] = []
         self._pending = []
         self._countdown = {}

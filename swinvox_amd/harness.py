@@ -19,9 +19,8 @@ import torch
 
 from . import hip
 from .hip import call, ptr
+from .losses import bce_with_logits as _bce      # torch.nn.BCEWithLogitsLoss() of core/train.py:165 on sv_bce_logits
 from .optim import FlatAdam, FlatSGD, _FlatSolver
-
-_bce = torch.nn.functional.binary_cross_entropy_with_logits
 
 
 def make_solvers(nets, cfg, fused: bool = True):
@@ -128,8 +127,16 @@ def voxel_metrics(volume, gt, thresholds):
 @torch.no_grad()
 def evaluate(nets, cfg, images, gt, epoch_idx: int = 0, with_fscore: bool = False):
     """Returns (encoder_loss*10, refiner_loss*10, iou[B, n_thresholds]) (+ fscore[B, n_thresholds] with_fscore=True) for a
-    batch, per sample and threshold as in core/test.py:120-163."""
-    total, el, rl, volume, _ = forward_losses(nets, cfg, images, gt, epoch_idx)
+    batch, per sample and threshold as in core/test.py:120-163.  The nets are switched to eval() for the pass (core/test.py:100-104:
+    running BatchNorm statistics, no dropout / drop-path, no statistics update) and put back into their previous mode."""
+    was_training = [n.training for n in nets]
+    for n in nets:
+        n.eval()
+    try:
+        total, el, rl, volume, _ = forward_losses(nets, cfg, images, gt, epoch_idx)
+    finally:
+        for n, t in zip(nets, was_training):
+            n.train(t)
     iou, fs = voxel_metrics(volume, gt, cfg.TEST.VOXEL_THRESH)
     return (el * 10, rl * 10, iou, fs) if with_fscore else (el * 10, rl * 10, iou)
 

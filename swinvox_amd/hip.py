@@ -114,8 +114,8 @@ _PROTOS = {
     "sv_binvox_decode": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "sv_augment_views": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sv_grad_sumsq": (_I, [_P, _L, _F, _P]),
-    "sv_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _L, _F, _P, _F]),
-    "sv_sgd_step": (_I, [_P, _P, _P, _L, _D, _D, _D, _I, _F, _P, _F]),
+    "sv_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _L, _F, _P, _F, _P]),
+    "sv_sgd_step": (_I, [_P, _P, _P, _L, _D, _D, _D, _L, _F, _P, _F, _P]),
 }
 
 
@@ -154,14 +154,18 @@ def load() -> C.CDLL:
     return _lib
 
 
-_DEV = [None]   # device index of the tensors of the running module (set by check_cuda): the raw-stream query needs it
+class _Dev(threading.local):
+    idx = None
+
+
+_DEV = _Dev()   # per thread: device index of the tensors of the running module (set by check_cuda): the raw-stream query needs it
 
 
 def _stream() -> int:
     """hipStream_t of torch's current stream (torch.cuda.current_stream() costs ~9 us per call; the raw query ~0.3 us)."""
-    d = _DEV[0]
+    d = _DEV.idx
     if d is None:
-        d = _DEV[0] = torch.cuda.current_device()
+        d = _DEV.idx = torch.cuda.current_device()
     return torch._C._cuda_getCurrentRawStream(d)
 
 
@@ -178,7 +182,7 @@ def check_cuda(*tensors) -> None:
             if not t.is_cuda:
                 raise RuntimeError("swinvox_amd: tensors must live on the GPU (no CPU path exists in the product); got "
                                    f"device={t.device}")
-            _DEV[0] = t.device.index
+            _DEV.idx = t.device.index
 
 
 class Tracer:
@@ -187,6 +191,7 @@ class Tracer:
 
     def __init__(self, names):
         self.names = set(names)
+        self.thread = threading.get_ident()    # launches of other threads are not traced (one open bracket at a time)
         self.records = []          # (name, start_event, end_event, algorithmic_flops, algorithmic_bytes)
         self._open = None
 
@@ -233,7 +238,7 @@ def call(name: str, *args, act=None) -> None:
     if name in _ACT_TYPED:
         args = args + (ACT if act is None else act,)
     tr = TRACE
-    if tr is not None and tr._open is None and name in tr.names:   # untimed-by-caller entry point selected for tracing
+    if tr is not None and tr._open is None and name in tr.names and tr.thread == threading.get_ident():   # untimed-by-caller entry point selected for tracing
         tr.begin(name)
         rc = getattr(lib, name)(*args, _stream())
         tr.end()

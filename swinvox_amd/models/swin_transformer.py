@@ -104,7 +104,8 @@ class SwinBackbone(_Holder):
             dim = embed_dim * 2 ** i
             if i > 0:
                 res //= 2
-            setattr(self, f"layers_{i}", SwinStage(dim_in, dim, res, d, heads[i], dps[ofs:ofs + d], i > 0))
+            if i <= max(self.out_indices):   # timm's FeatureListNet drops every module after the last requested stage
+                setattr(self, f"layers_{i}", SwinStage(dim_in, dim, res, d, heads[i], dps[ofs:ofs + d], i > 0))
             ofs, dim_in = ofs + d, dim
             chans.append(dim)
         self.feature_info = _FeatureInfo([chans[i] for i in self.out_indices])

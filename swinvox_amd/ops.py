@@ -8,6 +8,7 @@ dtype (fp32, or bf16 under set_storage("bf16")); parameters, their gradients and
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -16,7 +17,21 @@ import torch
 from . import hip
 from .hip import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, Epilogue, Geom, call, ptr  # noqa: F401
 
+# Process-wide CONFIGURATION (set_math / set_storage / set_overlap): read-only while modules run.
 _STATE = {"math": hip.MATH_F32, "store": torch.float32}
+
+
+class _CallContext(threading.local):
+    """Per-thread context of the module pass that is running on this thread (weight-pack cache, zero arena, weight-gradient
+    stream, BatchNorm tick list).  torch.nn.DataParallel (reference core/train.py:156-161) calls the modules' forward from
+    one Python thread per device, so nothing mutable on the launch path may be shared between threads."""
+    packs = None
+    arena = None
+    awg = None
+    bn_tick = None
+
+
+_CTX = _CallContext()
 BN_SLOTS = 16   # SV_BN_SLOTS of include/swinvox_hip.h
 BN_BWD_SLOTS, LN_BWD_SLOTS = 16, 32   # slot counts behind sv_bn_bwd_workspace_doubles / sv_layernorm_bwd_workspace_floats
 
@@ -162,7 +177,7 @@ class ConvSpec:
         dt = _STATE["store"]
         if kind == "f" and dt == torch.float32 and not self.transposed and self.taps == 1 and self.cin_mem == self.cin:
             return w  # Linear / 1x1 conv in fp32: the native layout already is the packed layout
-        cache = _STATE.get("packs")
+        cache = _CTX.packs
         if cache is not None:
             return cache.get(self, w, kind)
         return pack_one(self, w, kind)
@@ -180,7 +195,7 @@ class ConvSpec:
         """Launch a contraction; when bench.py's tracer is active, bracket it with HIP events and book its ALGORITHMIC
         work: 2 * positions * taps_that_contribute * cin * cout flops (no channel padding, no masked taps)."""
         tr = hip.TRACE
-        if tr is None or name not in tr.names:
+        if tr is None or name not in tr.names or tr.thread != threading.get_ident():
             return call(name, *args)
         og = self.out_grid(in_grid)
         if self.transposed:   # every input position meets every tap exactly once
@@ -224,7 +239,7 @@ class ConvSpec:
         Inside a module backward the launch goes to the weight-gradient stream (AsyncWgrad): nothing on the data-gradient
         chain waits for a weight gradient.  async_ok=False keeps it on the caller's stream - required when dy or x is
         modified in place afterwards."""
-        aw = _STATE.get("awg")
+        aw = _CTX.awg
         if aw is not None and async_ok:
             cur = torch.cuda.current_stream()
             aw.stream.wait_stream(cur)                 # dy and x are complete on the producing stream
@@ -342,20 +357,20 @@ class ZeroArena:
 
 
 def zeros_f64(n, dev):
-    a = _STATE.get("arena")
+    a = _CTX.arena
     return a.take(n, dev) if a is not None else torch.zeros(n, dtype=torch.float64, device=dev)
 
 
 def set_arena(arena) -> None:
-    _STATE["arena"] = arena
+    _CTX.arena = arena
 
 
 def bn_tick_flush() -> None:
     """num_batches_tracked += 1 for every BatchNorm that ran since the last flush, in one foreach launch."""
-    lst = _STATE.get("bn_tick")
+    lst = _CTX.bn_tick
     if lst:
         torch._foreach_add_(lst, 1)
-    _STATE["bn_tick"] = []
+    _CTX.bn_tick = []
 
 
 class AsyncWgrad:
@@ -375,7 +390,7 @@ class AsyncWgrad:
 
 
 def set_async_wgrad(aw) -> None:
-    _STATE["awg"] = aw
+    _CTX.awg = aw
 
 
 _SIDE = {}
@@ -405,7 +420,7 @@ def set_overlap(on: bool) -> None:
 
 def set_pack_cache(cache) -> None:
     """Route ConvSpec.pack_fwd / pack_dgrad through `cache` (a PackCache, or None for one launch per pack)."""
-    _STATE["packs"] = cache
+    _CTX.packs = cache
 
 
 def colsum(x, rows, cols, ld, out, accumulate=True):
@@ -457,7 +472,9 @@ class BatchNormState:
     def finalize(self):
         bn = self.bn
         if self.training and bn.num_batches_tracked is not None:
-            _STATE.setdefault("bn_tick", []).append(bn.num_batches_tracked)   # += 1 in one foreach launch (bn_tick_flush)
+            if _CTX.bn_tick is None:
+                _CTX.bn_tick = []
+            _CTX.bn_tick.append(bn.num_batches_tracked)   # += 1 in one foreach launch (bn_tick_flush)
         mom = bn.momentum if bn.momentum is not None else 0.1
         call("sv_bn_finalize", ptr(self.sums), self.M, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
              float(mom), float(bn.eps), 1 if self.training else 0, ptr(self.scale), ptr(self.shift), ptr(self.mean), ptr(self.rstd), self.C)

@@ -104,6 +104,7 @@ class _FlatSolver(torch.optim.Optimizer):
         self.flat_p = torch.zeros(self.layout.total, device=dev)
         self._gflat = None
         self.norm_slots = torch.zeros(16, dtype=torch.float64, device=dev)
+        self.skipped = torch.zeros(1, dtype=torch.int64, device=dev)   # steps the device skipped (non-finite gradient)
         self.steps = 0
         self._adopt()
 
@@ -138,24 +139,28 @@ class _FlatSolver(torch.optim.Optimizer):
         g = self._grad_address()
         if g is None:
             return None, None
-        slots = None
-        if clip_norm is not None and clip_norm > 0:
-            self.norm_slots.zero_()
-            call("sv_grad_sumsq", g, self.layout.total, float(grad_scale), ptr(self.norm_slots))
-            slots = ptr(self.norm_slots)
-        return g, slots
+        # the squared norm is always taken: it carries the clip coefficient AND the inf / NaN check that skips the step
+        self.norm_slots.zero_()
+        call("sv_grad_sumsq", g, self.layout.total, float(grad_scale), ptr(self.norm_slots))
+        return g, ptr(self.norm_slots)
 
     def grad_norm(self) -> torch.Tensor:
-        """L2 norm of the (scaled) gradient measured by the last clipped step (device tensor, no synchronisation)."""
+        """L2 norm of the (scaled) gradient measured by the last step (device tensor, no synchronisation)."""
         return self.norm_slots.sum().sqrt().float()
+
+    def skipped_steps(self) -> int:
+        """Number of steps skipped because the gradient held an inf / NaN (host read: synchronises)."""
+        return int(self.skipped.item())
 
     def state_dict(self):
         g = self.param_groups[0]
-        return {"steps": self.steps, "buffers": {k: v.clone() for k, v in self._buffers().items()},
+        return {"steps": self.steps, "skipped": self.skipped.clone(), "buffers": {k: v.clone() for k, v in self._buffers().items()},
                 "param_group": {k: v for k, v in g.items() if k != "params"}}
 
     def load_state_dict(self, sd):
         self.steps = int(sd["steps"])
+        if "skipped" in sd:
+            self.skipped.copy_(sd["skipped"])
         for k, v in self._buffers().items():
             v.copy_(sd["buffers"][k])
         self.param_groups[0].update(sd["param_group"])
@@ -183,7 +188,7 @@ class FlatAdam(_FlatSolver):
         h = self.param_groups[0]
         call("sv_adam_step", ptr(self.flat_p), g, ptr(self.exp_avg), ptr(self.exp_avg_sq), self.layout.total, float(h["lr"]),
              float(h["betas"][0]), float(h["betas"][1]), float(h["eps"]), float(h["weight_decay"]), self.steps, float(grad_scale),
-             slots, float(clip_norm or 0.0))
+             slots, float(clip_norm or 0.0), ptr(self.skipped))
         return None
 
 
@@ -207,5 +212,5 @@ class FlatSGD(_FlatSolver):
         self.steps += 1
         h = self.param_groups[0]
         call("sv_sgd_step", ptr(self.flat_p), g, ptr(self.momentum_buffer), self.layout.total, float(h["lr"]), float(h["momentum"]),
-             float(h["weight_decay"]), 1 if self.steps == 1 else 0, float(grad_scale), slots, float(clip_norm or 0.0))
+             float(h["weight_decay"]), self.steps, float(grad_scale), slots, float(clip_norm or 0.0), ptr(self.skipped))
         return None

@@ -56,6 +56,17 @@ def test_host_draws_follow_the_oracle_call_order():
     assert a.noise_alpha == pytest.approx(b["noise_alpha"].tolist())
     assert a.noise_rgb() == pytest.approx(OD.noise_rgb_of(b["noise_alpha"]))
     assert all(225 / 255 <= v <= 1.0 for v in a.bg) and all(0.6 < v < 1.4 for v in a.jitter_value)
+    # RGB renderings: RandomBackground draws nothing (data_transforms.py:428-430), so the jitter sees the first uniform draws
+    np.random.seed(11)
+    random.seed(12)
+    c = D.draw_train_params(5, cfg, n_channels=3)
+    np.random.seed(11)
+    random.seed(12)
+    d = OD.draw_train_params(5, dict(cfg.TRAIN), n_channels=3)
+    np.random.seed(11)
+    first = 1 + np.random.uniform(low=-cfg.TRAIN.BRIGHTNESS, high=cfg.TRAIN.BRIGHTNESS)
+    assert c.jitter_value[0] == pytest.approx(first) and c.jitter_value == pytest.approx(d["jitter_value"])
+    assert list(c.flips) == d["flips"] and c.jitter_value != pytest.approx(a.jitter_value)
     v = D.val_params(3, cfg)
     assert v.bg == pytest.approx([240 / 255] * 3) and list(v.flips) == [False] * 3 and list(v.jitter_value) == [1.0, 1.0, 1.0]
 

@@ -79,6 +79,32 @@ def test_reference_init_weights_applies_to_holders():
     assert 0 < float(m.layer2[0].weight.abs().max()) < 0.1
 
 
+def test_init_weights_matches_reference_recipe():
+    """swinvox_amd.helpers.init_weights (utils/helpers.py:20-44 inside the product) draws the same numbers as the oracle's
+    restatement from the same seed - on the HIP-backed holders and on the oracle modules - and touches every Conv/Linear/BN."""
+    from swinvox_amd.helpers import count_parameters, init_weights
+    for mk_p, mk_o in ((lambda: Decoder(S.default_cfg()), lambda: O.Decoder(O.default_cfg())),
+                       (lambda: Refiner(S.default_cfg()), lambda: O.Refiner(O.default_cfg())),
+                       (lambda: Encoder(S.default_cfg()), lambda: O.Encoder(O.default_cfg()))):
+        p, o = mk_p(), mk_o()
+        torch.manual_seed(5)
+        p.apply(init_weights)
+        torch.manual_seed(5)
+        o.apply(O.init_weights)
+        assert count_parameters(p) == count_parameters(o)
+        kinds = (torch.nn.modules.conv._ConvNd, torch.nn.Linear, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)
+        om, touched = dict(o.named_modules()), 0
+        for name, m in p.named_modules():       # everything the recipe touches (LayerNorms and bias tables keep their constructor values)
+            if isinstance(m, kinds):
+                for (k, a), (k2, b) in zip(m.named_parameters(recurse=False), om[name].named_parameters(recurse=False)):
+                    assert k == k2 and torch.equal(a, b), f"{name}.{k}"
+                    touched += a.numel()
+        assert touched > 0.95 * count_parameters(p) or isinstance(p, Encoder)
+    lin = torch.nn.Linear(64, 64)
+    init_weights(lin)
+    assert float(lin.bias.abs().max()) == 0.0 and 5e-4 < float(lin.weight.std()) < 2e-3     # N(0, 0.01) * 0.1
+
+
 def test_oracle_matches_golden_vectors():
     cfg = O.default_cfg()
     nets = [O.Encoder(cfg), O.Decoder(cfg), O.Merger(cfg), O.Refiner(cfg)]
@@ -88,7 +114,7 @@ def test_oracle_matches_golden_vectors():
     for n in nets:
         n.eval()
     man = json.load(open(os.path.join(GOLD, "manifest.json")))["cases"]
-    for key in ("B2_V1", "B1_V2"):
+    for key in ("B2_V1", "B1_V2", "B2_V8"):
         B, V = int(key[1]), int(key[4])
         gold = np.load(os.path.join(GOLD, f"case_{key}.npz"))
         x, gt = synth_images(B, V, man[key]["seed"]), synth_gt(B, man[key]["seed"])

@@ -51,8 +51,17 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from swinvox_amd.dp import GradAllReducer, shard_batch
     nets = _make_nets()
+    # every rank starts from DIFFERENT weights and BatchNorm statistics: the reducer's constructor must make them rank 0's
+    if rank != 0:
+        with torch.no_grad():
+            for n in nets:
+                for t in list(n.parameters()) + list(n.buffers()):
+                    t.add_(1) if t.dtype.is_floating_point else t.add_(3)
     reducer = GradAllReducer([nets[2], nets[1], nets[0]], bucket_bytes=8 << 20)   # several buckets for the refiner
     assert len(reducer.buckets) > 3
+    for n, r in zip(nets, _make_nets()):
+        for (k, a), (_, b) in zip(n.state_dict().items(), r.state_dict().items()):
+            assert torch.equal(a, b), f"rank {rank}: {k} differs from rank 0 after construction"
     feat, gt = _data()
     for step in range(2):   # two steps: hooks / countdowns must re-arm
         for n in nets:

@@ -90,8 +90,40 @@ def test_flat_solver_edge_cases(dev):
     fa.step()
     assert fa.layout.locate([p.data for p in a.parameters()]) == fa.flat_p.data_ptr()
     lib = hip.load()
-    assert lib.sv_adam_step(fa.flat_p.data_ptr() + 4, 0, 0, 0, 16, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None, 0.0, None) != 0
+    assert lib.sv_adam_step(fa.flat_p.data_ptr() + 4, 0, 0, 0, 16, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None, 0.0, None, None) != 0
     assert b"adam_step" in lib.sv_last_error()
+
+
+@pytest.mark.parametrize("kind", ["adam", "sgd"])
+@pytest.mark.parametrize("clip", [1.0, None])
+def test_non_finite_gradient_skips_the_step(dev, kind, clip):
+    """One inf / NaN gradient element: parameters and moments stay untouched and the skipped step does not count for the
+    bias correction - torch.amp.GradScaler.step() semantics of the reference (core/train.py:276-293) - with and without
+    clipping; the following finite steps equal a stock optimizer that never saw the bad step."""
+    a, b = _pair(dev)
+    if kind == "adam":
+        kw = dict(lr=1e-2, betas=(0.85, 0.993), weight_decay=3.37e-4)
+        fa, tb = FlatAdam(a.parameters(), **kw), torch.optim.Adam(b.parameters(), **kw)
+    else:
+        kw = dict(lr=0.05, momentum=0.9, weight_decay=1e-3)
+        fa, tb = FlatSGD(a.parameters(), **kw), torch.optim.SGD(b.parameters(), **kw)
+    for step, bad in enumerate([None, float("inf"), None, float("nan"), None]):
+        gflat = _set_grads(a, b, step, 0.5, True)
+        before = fa.flat_p.clone()
+        bufs = {k: v.clone() for k, v in fa._buffers().items()}
+        if bad is not None:
+            gflat[5] = bad
+            fa.step(clip_norm=clip)
+            assert torch.equal(fa.flat_p, before) and all(torch.equal(v, bufs[k]) for k, v in fa._buffers().items())
+            continue
+        if clip:
+            torch.nn.utils.clip_grad_norm_(list(b.parameters()), max_norm=clip)
+        tb.step()
+        fa.step(clip_norm=clip)
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert float((pa - pb).abs().max()) <= 2e-6 * max(1.0, float(pb.abs().max())), step
+    assert fa.skipped_steps() == 2 and fa.steps == 5
+    assert bool(torch.isfinite(fa.flat_p).all())
 
 
 def test_train_step_with_flat_solvers_matches_stock_solvers(dev):
