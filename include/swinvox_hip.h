@@ -154,10 +154,10 @@ int sv_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
                      int accumulate_dx, int act_dtype, void* stream);
 size_t sv_ln_image_workspace_floats(int I, int L);
 int sv_ln_image_fwd(const void* x, const float* w, const float* b, void* y, float* meanrstd, float* workspace,
-                    int I, int L, float eps, float drop_p, uint32_t seed, int act_dtype, void* stream);
+                    int I, int L, float eps, float drop_p, uint32_t seed, const uint32_t* seed_epoch, int act_dtype, void* stream);
 int sv_ln_image_bwd(const void* dy, const void* x, const float* w, const float* meanrstd, void* dx, float* dw,
-                    float* db, double* sums_ws /* [2*I] doubles */, int I, int L, float drop_p, uint32_t seed, int act_dtype,
-                    void* stream);
+                    float* db, double* sums_ws /* [2*I] doubles */, int I, int L, float drop_p, uint32_t seed,
+                    const uint32_t* seed_epoch, int act_dtype, void* stream);
 int sv_bn_stats(const void* x, long long M, int C, int ld, double* sums, int act_dtype, void* stream);   /* sums: [SV_BN_SLOTS][2*C] doubles (slot 0 is used) */
 int sv_bn_finalize(const double* sums, long long count, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float momentum, float eps, int training, float* scale, float* shift,
@@ -213,8 +213,10 @@ int sv_decoder_seed_fwd(const void* feat, void* out, int I, int C, int act_dtype
 int sv_decoder_seed_bwd(const void* dout, void* dfeat, int I, int C, int act_dtype, void* stream);
 int sv_maxpool3d_fwd(const void* x, void* y, uint8_t* idx, int N, int D, int H, int W, int C, int act_dtype, void* stream); /* refiner.py:25,31,37 */
 int sv_maxpool3d_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int D, int H, int W, int C, int act_dtype, void* stream);
-int sv_dropout(const void* x, void* y, long long n, float p, uint32_t seed, int act_dtype, void* stream);            /* cross_view_attention.py:57,131 */
-int sv_droppath_scale(float* scale, int I, float p, uint32_t seed, void* stream);                        /* timm DropPath */
+/* seed_epoch (all stochastic entry points; may be NULL): device word mixed into `seed` on the device, so that launches replayed
+ * from a captured hipGraph - whose scalar arguments are frozen - draw fresh masks when the caller advances the word per replay. */
+int sv_dropout(const void* x, void* y, long long n, float p, uint32_t seed, const uint32_t* seed_epoch, int act_dtype, void* stream);            /* cross_view_attention.py:57,131 */
+int sv_droppath_scale(float* scale, int I, float p, uint32_t seed, const uint32_t* seed_epoch, void* stream);                        /* timm DropPath */
 int sv_rowscale(const void* x, const float* scale, void* y, long long rows, int C, int rows_per_scale, int act_dtype, void* stream);
 int sv_dwconv2x2_fwd(const void* x, const float* w, const float* b, void* y, int I, int C, int act_dtype, void* stream); /* cross_view_attention.py:26-32,68 */
 int sv_dwconv2x2_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, float* db, int I, int C, int act_dtype, void* stream);

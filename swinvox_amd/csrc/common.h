@@ -193,6 +193,12 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t seed, uint32_t idx_lo, uin
   x += idx_lo; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
   return x;
 }
+// seed of a launch that may be replayed from a hipGraph: the scalar argument is frozen at capture time, so the caller can
+// pass a device word (`epoch`, advanced once per replay) that is mixed in on the device - every replay draws new masks,
+// the backward of the same replay sees the same word as its forward.  epoch == nullptr: the scalar seed alone.
+__device__ __forceinline__ uint32_t eff_seed(uint32_t seed, const uint32_t* epoch) {
+  return epoch ? seed + epoch[0] * 0x9E3779B1u : seed;
+}
 __device__ __forceinline__ float uniform01(uint32_t seed, uint64_t idx) {
   return (hash_u32(seed, (uint32_t)idx, (uint32_t)(idx >> 32)) >> 8) * (1.0f / 16777216.0f);
 }

@@ -240,13 +240,16 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const AT* __restrict
 
 // ---- dropout (same kernel forward and backward: y = x * mask / keep, mask from (seed, element index))
 template <typename AT>
-__global__ __launch_bounds__(256) void dropout_kernel(const AT* __restrict__ x, AT* __restrict__ y, long long n, float p, uint32_t seed) {
+__global__ __launch_bounds__(256) void dropout_kernel(const AT* __restrict__ x, AT* __restrict__ y, long long n, float p, uint32_t seed,
+                                                      const uint32_t* __restrict__ epoch) {
+  seed = eff_seed(seed, epoch);
   const float keep_inv = 1.f / (1.f - p);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
     stf(y + i, uniform01(seed, (uint64_t)i) < p ? 0.f : ldf(x + i) * keep_inv);
 }
 // per-image drop-path factors: scale[i] = 0 or 1/keep
-__global__ void droppath_scale_kernel(float* __restrict__ scale, int I, float p, uint32_t seed) {
+__global__ void droppath_scale_kernel(float* __restrict__ scale, int I, float p, uint32_t seed, const uint32_t* __restrict__ epoch) {
+  seed = eff_seed(seed, epoch);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < I) scale[i] = uniform01(seed, (uint64_t)i) < p ? 0.f : 1.f / (1.f - p);
 }
@@ -607,15 +610,15 @@ extern "C" int sv_maxpool3d_bwd(const void* dy, const uint8_t* idx, void* dx, in
   SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(maxpool3d_bwd_kernel<AT>, dim3(grid_for((long long)N * D * H * W * C)), dim3(256), 0, STREAM, CA(dy), idx, MA(dx), N, D, H, W, C););
   return check_launch("sv_maxpool3d_bwd");
 }
-extern "C" int sv_dropout(const void* x, void* y, long long n, float p, uint32_t seed, int act_dtype, void* stream) {
+extern "C" int sv_dropout(const void* x, void* y, long long n, float p, uint32_t seed, const uint32_t* seed_epoch, int act_dtype, void* stream) {
   SV_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
   SV_REQUIRE_ACT(act_dtype);
-  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(dropout_kernel<AT>, dim3(grid_for(n)), dim3(256), 0, STREAM, CA(x), MA(y), n, p, seed););
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(dropout_kernel<AT>, dim3(grid_for(n)), dim3(256), 0, STREAM, CA(x), MA(y), n, p, seed, seed_epoch););
   return check_launch("sv_dropout");
 }
-extern "C" int sv_droppath_scale(float* scale, int I, float p, uint32_t seed, void* stream) {
+extern "C" int sv_droppath_scale(float* scale, int I, float p, uint32_t seed, const uint32_t* seed_epoch, void* stream) {
   SV_REQUIRE(scale && I > 0 && p >= 0.f && p < 1.f, "droppath_scale: bad arguments");
-  hipLaunchKernelGGL(droppath_scale_kernel, dim3(cdiv(I, 64)), dim3(64), 0, STREAM, scale, I, p, seed);
+  hipLaunchKernelGGL(droppath_scale_kernel, dim3(cdiv(I, 64)), dim3(64), 0, STREAM, scale, I, p, seed, seed_epoch);
   return check_launch("sv_droppath_scale");
 }
 extern "C" int sv_rowscale(const void* x, const float* scale, void* y, long long rows, int C, int rows_per_scale, int act_dtype, void* stream) {

@@ -273,7 +273,8 @@ __global__ void lnl_finalize_kernel(const float* __restrict__ part, float* __res
 template <typename AT>
 __global__ __launch_bounds__(256) void lnl_apply_kernel(const AT* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, const float* __restrict__ meanrstd,
-                                                        AT* __restrict__ y, int L, float drop_p, uint32_t seed) {
+                                                        AT* __restrict__ y, int L, float drop_p, uint32_t seed, const uint32_t* __restrict__ epoch) {
+  seed = eff_seed(seed, epoch);
   const int img = blockIdx.y;
   const float mean = meanrstd[img * 2], rstd = meanrstd[img * 2 + 1];
   const float keep_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(256) void lnl_apply_kernel(const AT* __restrict__ x
 template <typename AT>
 __global__ __launch_bounds__(256) void lnl_bwd_reduce_kernel(const AT* __restrict__ dy, const AT* __restrict__ x,
                                                              const float* __restrict__ w, const float* __restrict__ meanrstd,
-                                                             double* __restrict__ sums, int L, float drop_p, uint32_t seed) {
+                                                             double* __restrict__ sums, int L, float drop_p, uint32_t seed, const uint32_t* __restrict__ epoch) {
+  seed = eff_seed(seed, epoch);
   __shared__ float sc[4];
   const int img = blockIdx.y;
   const float mean = meanrstd[img * 2], rstd = meanrstd[img * 2 + 1];
@@ -324,7 +326,8 @@ __global__ __launch_bounds__(256) void lnl_bwd_apply_kernel(const AT* __restrict
                                                             const float* __restrict__ w, const float* __restrict__ meanrstd,
                                                             const double* __restrict__ sums, AT* __restrict__ dx,
                                                             float* __restrict__ dw, float* __restrict__ db, int L, int I,
-                                                            float drop_p, uint32_t seed) {
+                                                            float drop_p, uint32_t seed, const uint32_t* __restrict__ epoch) {
+  seed = eff_seed(seed, epoch);
   const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (e >= L) return;
   const float keep_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -883,7 +886,7 @@ extern "C" int sv_layernorm_bwd(const void* dy, const void* x, const float* gamm
 extern "C" size_t sv_ln_image_workspace_floats(int I, int L) { return (size_t)I * cdiv(L, LNL_CHUNK) * 2; }
 
 extern "C" int sv_ln_image_fwd(const void* x, const float* w, const float* b, void* y, float* meanrstd, float* workspace,
-                               int I, int L, float eps, float drop_p, uint32_t seed, int act_dtype, void* stream) {
+                               int I, int L, float eps, float drop_p, uint32_t seed, const uint32_t* seed_epoch, int act_dtype, void* stream) {
   SV_REQUIRE(x && w && b && y && meanrstd && workspace && I > 0 && L > 0 && L % 4 == 0, "ln_image_fwd: bad arguments (I=%d L=%d)", I, L);
   SV_REQUIRE_ACT(act_dtype);
   hipStream_t s = (hipStream_t)stream;
@@ -892,21 +895,21 @@ extern "C" int sv_ln_image_fwd(const void* x, const float* w, const float* b, vo
   SV_DISPATCH_ACT(act_dtype,
     hipLaunchKernelGGL(lnl_moments_kernel<AT>, dim3(nch, I), dim3(256), 0, s, static_cast<const AT*>(x), workspace, L, nch);
     hipLaunchKernelGGL(lnl_finalize_kernel, dim3(cdiv(I, 64)), dim3(64), 0, s, workspace, meanrstd, L, nch, eps, I);
-    hipLaunchKernelGGL(lnl_apply_kernel<AT>, dim3(gx, I), dim3(256), 0, s, static_cast<const AT*>(x), w, b, meanrstd, static_cast<AT*>(y), L, drop_p, seed););
+    hipLaunchKernelGGL(lnl_apply_kernel<AT>, dim3(gx, I), dim3(256), 0, s, static_cast<const AT*>(x), w, b, meanrstd, static_cast<AT*>(y), L, drop_p, seed, seed_epoch););
   return check_launch("sv_ln_image_fwd");
 }
 
 extern "C" int sv_ln_image_bwd(const void* dy, const void* x, const float* w, const float* meanrstd, void* dx, float* dw,
-                               float* db, double* sums_ws, int I, int L, float drop_p, uint32_t seed, int act_dtype, void* stream) {
+                               float* db, double* sums_ws, int I, int L, float drop_p, uint32_t seed, const uint32_t* seed_epoch, int act_dtype, void* stream) {
   SV_REQUIRE(dy && x && w && meanrstd && dx && dw && db && sums_ws && I > 0 && L > 0 && L % 4 == 0, "ln_image_bwd: bad arguments");
   SV_REQUIRE_ACT(act_dtype);
   hipStream_t s = (hipStream_t)stream;
   (void)hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * I, s);
   int gx = cdiv(L, 1024); if (gx > 32) gx = 32;
   SV_DISPATCH_ACT(act_dtype,
-    hipLaunchKernelGGL(lnl_bwd_reduce_kernel<AT>, dim3(gx, I), dim3(256), 0, s, static_cast<const AT*>(dy), static_cast<const AT*>(x), w, meanrstd, sums_ws, L, drop_p, seed);
+    hipLaunchKernelGGL(lnl_bwd_reduce_kernel<AT>, dim3(gx, I), dim3(256), 0, s, static_cast<const AT*>(dy), static_cast<const AT*>(x), w, meanrstd, sums_ws, L, drop_p, seed, seed_epoch);
     hipLaunchKernelGGL(lnl_bwd_apply_kernel<AT>, dim3(cdiv(L, 1024)), dim3(256), 0, s, static_cast<const AT*>(dy), static_cast<const AT*>(x), w, meanrstd, sums_ws,
-                       static_cast<AT*>(dx), dw, db, L, I, drop_p, seed););
+                       static_cast<AT*>(dx), dw, db, L, I, drop_p, seed, seed_epoch););
   return check_launch("sv_ln_image_bwd");
 }
 

@@ -74,8 +74,8 @@ _PROTOS = {
     "sv_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I]),
     "sv_bn_bwd_workspace_doubles": (C.c_size_t, None, [_I]),
     "sv_ln_image_workspace_floats": (C.c_size_t, None, [_I, _I]),
-    "sv_ln_image_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U]),
-    "sv_ln_image_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U]),
+    "sv_ln_image_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U, _P]),
+    "sv_ln_image_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P]),
     "sv_bn_stats": (_I, [_P, _L, _I, _I, _P]),
     "sv_bn_finalize": (_I, [_P, _L, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _I]),
     "sv_scale_shift_act": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _F]),
@@ -97,8 +97,8 @@ _PROTOS = {
     "sv_decoder_seed_bwd": (_I, [_P, _P, _I, _I]),
     "sv_maxpool3d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
     "sv_maxpool3d_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
-    "sv_dropout": (_I, [_P, _P, _L, _F, _U]),
-    "sv_droppath_scale": (_I, [_P, _I, _F, _U]),
+    "sv_dropout": (_I, [_P, _P, _L, _F, _U, _P]),
+    "sv_droppath_scale": (_I, [_P, _I, _F, _U, _P]),
     "sv_rowscale": (_I, [_P, _P, _P, _L, _I, _I]),
     "sv_dwconv2x2_fwd": (_I, [_P, _P, _P, _P, _I, _I]),
     "sv_dwconv2x2_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I]),
@@ -191,9 +191,16 @@ class Tracer:
 
     def __init__(self, names):
         self.names = set(names)
-        self.thread = threading.get_ident()    # launches of other threads are not traced (one open bracket at a time)
         self.records = []          # (name, start_event, end_event, algorithmic_flops, algorithmic_bytes)
-        self._open = None
+        self._tls = threading.local()    # the open bracket is per thread (autograd runs a module's backward on its own thread)
+
+    @property
+    def _open(self):
+        return getattr(self._tls, "open", None)
+
+    @_open.setter
+    def _open(self, v):
+        self._tls.open = v
 
     def begin(self, name, flops=0.0, nbytes=0.0, tag=""):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -238,7 +245,7 @@ def call(name: str, *args, act=None) -> None:
     if name in _ACT_TYPED:
         args = args + (ACT if act is None else act,)
     tr = TRACE
-    if tr is not None and tr._open is None and name in tr.names and tr.thread == threading.get_ident():   # untimed-by-caller entry point selected for tracing
+    if tr is not None and tr._open is None and name in tr.names:   # untimed-by-caller entry point selected for tracing
         tr.begin(name)
         rc = getattr(lib, name)(*args, _stream())
         tr.end()

@@ -93,6 +93,31 @@ class HipModule(nn.Module):
     _bwd(tape, grads, in_needs, *douts) -> d_inputs."""
 
     stochastic = True  # dropout / drop-path active in train() (set False for deterministic gradient parity tests)
+    # Data-parallel hand-off (dp.GradAllReducer): a module whose backward completes groups of parameter gradients early lists the
+    # groups in grad_groups() (contiguous runs of the registration order) and calls _announce(grads, k) once group k is enqueued;
+    # the hook then starts that group's all-reduce beside the rest of the backward.  None: nobody listens.
+    grad_ready_hook = None
+
+    def _announce(self, grads: "GradStore", group_index: int) -> None:
+        hook = self.grad_ready_hook
+        if hook is None:
+            return
+        views = [grads[p] for p in self.grad_groups()[group_index] if p.requires_grad]
+        if not views:
+            return
+        if not views[0].is_cuda:
+            hook(group_index, views)
+            return
+        # the group's gradients were written by the current stream and by the weight-gradient stream: a staging stream waits
+        # for both (neither of them is stalled) and the collective is enqueued behind it
+        cur = torch.cuda.current_stream()
+        cs = ops.comm_stream(views[0].device)
+        cs.wait_stream(cur)
+        aw = ops._CTX.awg
+        if aw is not None:
+            cs.wait_stream(aw.stream)
+        with torch.cuda.stream(cs):
+            hook(group_index, views)
 
     def _param_list(self) -> List[torch.Tensor]:
         """Parameters in registration order (cached: walking the module tree costs ~1 ms per call on the encoder).  The

@@ -68,7 +68,7 @@ class CrossViewAttention(nn.Module):
         if p > 0:
             seed = seeds()
             out = empty(I * 49, C, like=x)
-            call("sv_dropout", ptr(z), ptr(out), z.numel(), float(p), seed)
+            call("sv_dropout", ptr(z), ptr(out), z.numel(), float(p), seed, ops.seed_epoch_ptr())
         return out, (x, dw, qkv, att, up, f1pre, f1, f2, st, p, seed, B, V)
 
     def cva_backward(self, ctx, dout, grads):
@@ -77,7 +77,7 @@ class CrossViewAttention(nn.Module):
         dz = dout
         if p > 0:
             dz = empty(I * 49, C, like=x)
-            call("sv_dropout", ptr(dout), ptr(dz), dz.numel(), float(p), seed)
+            call("sv_dropout", ptr(dout), ptr(dz), dz.numel(), float(p), seed, ops.seed_epoch_ptr())
         df2 = empty(I * 49, C, like=x)
         st.backward(dz, C, None, 0, f2, C, df2, C, grads[self.batch_norm.weight], grads[self.batch_norm.bias], ACT_NONE)
         ops.linear_wgrad(df2, f1, I * 49, self._s_f2, grads[self.ffn[2].weight], grads[self.ffn[2].bias])

@@ -105,6 +105,16 @@ class Encoder(HipModule):
         else:
             self._s_red1 = ConvSpec.linear(self.swin_reduce.in_channels, 256)
 
+    def grad_groups(self):
+        """Parameter groups in the order their gradients complete inside _bwd (each a contiguous run of the registration order):
+        0 = everything behind the two backbones (resnet_reduce, Swin neck, cross-view attention, fusion + conv blocks),
+        1 = the Swin backbone + stage heads, 2 = the ResNet trunk."""
+        res = list(self.resnet.parameters())
+        swin = list(self.swin_transformer.parameters())
+        skip = {id(p) for p in res} | {id(p) for p in swin}
+        tail = [p for p in self.parameters() if id(p) not in skip]
+        return [tail, swin, res]
+
     def forward(self, rendering_images):
         assert rendering_images.dim() == 5 and rendering_images.shape[2] == 3, "expected [B, V, 3, H, W]"
         assert tuple(rendering_images.shape[-2:]) == (224, 224), "swinvox_amd: images must be 224x224 (reference cfg.CONST.IMG_H/W)"
@@ -277,10 +287,14 @@ class Encoder(HipModule):
                     hw, ch = self.swin_transformer.out_spatial[i], self.swin_transformer.out_channels[i]
                     dfeats[i] = zeros(I * hw * hw, ch, like=dout)
             swin_backward(self.swin_transformer, swin_tape, dfeats, I, grads, dready)
+            self._announce(grads, 1)                                       # Swin backbone + stage heads are enqueued
         # ---- ResNet branch
         drr = empty(I * 196, 256, like=dout)
         call("sv_avgpool2_bwd", ptr(dcat), ptr(drr), I, 14, 14, 256, 512, 0)
         self._s_rr.wgrad(drr, res_feat, I * 196, (1, 1, 1), grads[self.resnet_reduce.weight], db=grads[self.resnet_reduce.bias])
+        tail_on_main = multi or side is main                               # single-stage: swin_reduce's gradient is written on the side stream
+        if tail_on_main:
+            self._announce(grads, 0)                                       # neck + cross-view attention + fusion head are enqueued
         d = empty(I * 196, 1024, like=dout)
         self._s_rr.dgrad(drr, I * 196, (1, 1, 1), self._s_rr.pack_dgrad(self.resnet_reduce.weight), d)
         for blk, c in reversed(c_blocks):
@@ -288,5 +302,8 @@ class Encoder(HipModule):
         dmp = empty(I * 112 * 112, 64, like=dout)                            # the gather-form max-pool backward writes every element
         call("sv_maxpool2d_bwd", ptr(d), ptr(mp_idx), ptr(dmp), I, 112, 112, 64)
         self._stem_bwd(c_stem, dmp, grads)
+        self._announce(grads, 2)                                           # ResNet trunk
         main.wait_stream(side)                                             # join: every parameter gradient is complete
+        if not tail_on_main:
+            self._announce(grads, 0)
         return (None,)

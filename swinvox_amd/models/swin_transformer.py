@@ -135,7 +135,7 @@ class SwinTransformer(_Holder):
 # ---------------------------------------------------------------------------------------------------
 def _drop_scale(I, p, seed, like):
     sc = fempty(I, like=like)
-    call("sv_droppath_scale", ptr(sc), I, float(p), int(seed))
+    call("sv_droppath_scale", ptr(sc), I, float(p), int(seed), ops.seed_epoch_ptr())
     return sc
 
 
@@ -245,7 +245,7 @@ def swin_forward(st: SwinTransformer, img_nhwc, I, training, stochastic, seeds, 
             ws = fempty(int(hipws(I, L)), like=x)
             p = st.dropout.p if (training and stochastic) else 0.0
             seed = seeds() if p > 0 else 0
-            call("sv_ln_image_fwd", ptr(x), ptr(wt), ptr(bt), ptr(y), ptr(mr), ptr(ws), I, L, float(ln.eps), float(p), seed)
+            call("sv_ln_image_fwd", ptr(x), ptr(wt), ptr(bt), ptr(y), ptr(mr), ptr(ws), I, L, float(ln.eps), float(p), seed, ops.seed_epoch_ptr())
             tape["heads"].append((si, head_i, x, wt, mr, p, seed, L))
             feats.append(y)
             if ready is not None:
@@ -280,7 +280,7 @@ def swin_backward(st: SwinTransformer, tape, dfeats, I, grads, ready=None):
             dxe = empty(I * Hs * Hs, Cs, like=xs)
             dwt, dbt = fzeros(L, like=xs), fzeros(L, like=xs)
             sums = torch.empty(2 * I, dtype=torch.float64, device=xs.device)
-            call("sv_ln_image_bwd", ptr(dfeats[hi]), ptr(xs), ptr(wt), ptr(mr), ptr(dxe), ptr(dwt), ptr(dbt), ptr(sums), I, L, float(p), seed)
+            call("sv_ln_image_bwd", ptr(dfeats[hi]), ptr(xs), ptr(wt), ptr(mr), ptr(dxe), ptr(dwt), ptr(dbt), ptr(sums), I, L, float(p), seed, ops.seed_epoch_ptr())
             ops.transpose(dwt, grads[ln.weight], 1, Hs * Hs, Cs)   # [HW,C] -> [C,HW]
             ops.transpose(dbt, grads[ln.bias], 1, Hs * Hs, Cs)
             if dx is None:

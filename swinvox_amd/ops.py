@@ -195,7 +195,7 @@ class ConvSpec:
         """Launch a contraction; when bench.py's tracer is active, bracket it with HIP events and book its ALGORITHMIC
         work: 2 * positions * taps_that_contribute * cin * cout flops (no channel padding, no masked taps)."""
         tr = hip.TRACE
-        if tr is None or name not in tr.names or tr.thread != threading.get_ident():
+        if tr is None or name not in tr.names:
             return call(name, *args)
         og = self.out_grid(in_grid)
         if self.transposed:   # every input position meets every tap exactly once
@@ -407,6 +407,31 @@ def side_stream(dev) -> "torch.cuda.Stream":
         # high priority: the Swin backbone that runs here is the longer of the two encoder branches (measured +0.35 %)
         _SIDE[key] = torch.cuda.Stream(device=dev, priority=-1)
     return _SIDE[key]
+
+
+def set_seed_epoch(t: Optional[torch.Tensor]) -> None:
+    """Device word (int32/uint32 tensor with one element, or None) that every stochastic launch mixes into its scalar seed ON
+    THE DEVICE.  A captured hipGraph freezes scalar kernel arguments; a caller that replays a graph advances this word once per
+    replay (graph.GraphedStep does) so that dropout / drop-path masks differ from step to step.  Process-wide configuration."""
+    if t is not None and (not t.is_cuda or t.numel() != 1 or t.element_size() != 4):
+        raise ValueError("seed epoch must be a one-element 32-bit tensor on the GPU")
+    _STATE["seed_epoch"] = t
+
+
+def seed_epoch_ptr():
+    t = _STATE.get("seed_epoch")
+    return t.data_ptr() if t is not None else None
+
+
+_COMM = {}
+
+
+def comm_stream(dev) -> "torch.cuda.Stream":
+    """Staging stream of the data-parallel gradient hand-off (HipModule._announce)."""
+    key = (dev.type, dev.index)
+    if key not in _COMM:
+        _COMM[key] = torch.cuda.Stream(device=dev)
+    return _COMM[key]
 
 
 def overlap_enabled() -> bool:

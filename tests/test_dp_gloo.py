@@ -81,8 +81,82 @@ def _worker(rank, world, port, q):
         p.grad = v
     red2.finish()
     assert lin.weight.grad.data_ptr() == flat.data_ptr() and all(bool((p.grad == 1.5).all()) for p in lin.parameters())
+    _early_group_check(rank, world)
     dist.barrier()
     dist.destroy_process_group()
+
+
+class _ToyFn(torch.autograd.Function):
+    """Stand-in for models/_base.py::_ModuleFn on the CPU: ONE autograd node for the module, gradients returned as views of one
+    flat buffer in the FlatLayout of the parameter list, parameter groups announced INSIDE the backward (HipModule._announce)."""
+
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        ctx.mod, ctx.x = mod, x
+        with torch.no_grad():
+            return mod.b(torch.relu(mod.a(x)))
+
+    @staticmethod
+    def backward(ctx, dout):
+        from swinvox_amd.optim import FlatLayout
+        mod = ctx.mod
+        params = list(mod.parameters())
+        with torch.enable_grad():
+            gs = torch.autograd.grad(mod.b(torch.relu(mod.a(ctx.x))), params, dout)
+        lay = FlatLayout(params)
+        flat = torch.zeros(lay.total)
+        views = lay.views(flat)
+        for v, g_ in zip(views, gs):
+            v.copy_(g_)
+        by_id = {id(p): v for p, v in zip(params, views)}
+        mod.announced = []
+        for k, grp in enumerate(mod.grad_groups()):          # group 0 (the later layer) completes first, as in a real backward
+            if mod.grad_ready_hook is not None:
+                mod.grad_ready_hook(k, [by_id[id(p)] for p in grp])
+                mod.announced.append(k)
+        return (None, None) + tuple(views)
+
+
+class _Toy(torch.nn.Module):
+    grad_ready_hook = None
+
+    def __init__(self):
+        super().__init__()
+        self.a, self.b = torch.nn.Linear(6, 5), torch.nn.Linear(5, 3)
+
+    def grad_groups(self):
+        return [list(self.b.parameters()), list(self.a.parameters())]
+
+    def forward(self, x):
+        return _ToyFn.apply(self, x, *self.parameters())
+
+
+def _early_group_check(rank, world):
+    """Split buckets: a module that announces parameter groups inside its backward gets each group reduced from the announcement
+    (in place on its slice of the flat buffer); the post-accumulate hooks that fire afterwards must not reduce them again."""
+    from swinvox_amd.dp import GradAllReducer
+    torch.manual_seed(7)
+    toy, tail = _Toy(), torch.nn.Linear(3, 2)
+    red = GradAllReducer([tail, toy])
+    assert len(red.buckets) == 3 and red.stats()["early_groups"] == 2 and toy.grad_ready_hook is not None
+    g = torch.Generator().manual_seed(11)
+    xs = torch.randn(4, 6, generator=g)
+    for step in range(2):
+        for m in (toy, tail):
+            m.zero_grad(set_to_none=True)
+        tail(toy(xs[rank * 2:(rank + 1) * 2])).square().mean().backward()
+        assert toy.announced == [0, 1]
+        launched = len(red._pending)
+        red.finish()
+        assert launched == 3, launched            # two early groups + the tail module's bucket, nothing twice
+    ref_toy, ref_tail = _Toy(), torch.nn.Linear(3, 2)
+    ref_toy.load_state_dict(toy.state_dict()); ref_tail.load_state_dict(tail.state_dict())
+    ref_toy.grad_ready_hook = None
+    ref_tail(ref_toy(xs)).square().mean().backward()          # single process, whole batch = mean of the two shards' gradients
+    for (k, p), q in zip(list(toy.named_parameters()) + list(tail.named_parameters()), list(ref_toy.parameters()) + list(ref_tail.parameters())):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), (rank, k)
+    red.remove()
+    assert toy.grad_ready_hook is None
 
 
 @pytest.mark.timeout(600)

@@ -179,11 +179,11 @@ def test_ln_image(dev):
         mr = ops.fempty(2 * I, device=dev)
         nws = int(hip.load().sv_ln_image_workspace_floats(I, L))
         ws = ops.fempty(nws, device=dev)
-        call("sv_ln_image_fwd", ptr(xd), ptr(D(w, dev)), ptr(D(b, dev)), ptr(y), ptr(mr), ptr(ws), I, L, 1e-5, 0.05, 77)
+        call("sv_ln_image_fwd", ptr(xd), ptr(D(w, dev)), ptr(D(b, dev)), ptr(y), ptr(mr), ptr(ws), I, L, 1e-5, 0.05, 77, None)
         dx = ops.empty(I, L, device=dev)
         dw, db = ops.fzeros(L, device=dev), ops.fzeros(L, device=dev)
         sums = torch.empty(2 * I, dtype=torch.float64, device=dev)
-        call("sv_ln_image_bwd", ptr(A(dy)), ptr(xd), ptr(D(w, dev)), ptr(mr), ptr(dx), ptr(dw), ptr(db), ptr(sums), I, L, 0.05, 77)
+        call("sv_ln_image_bwd", ptr(A(dy)), ptr(xd), ptr(D(w, dev)), ptr(mr), ptr(dx), ptr(dw), ptr(db), ptr(sums), I, L, 0.05, 77, None)
         return dict(y=y, dx=dx, dw=dw, db=db)
 
     both(run, dev)
@@ -283,7 +283,7 @@ def test_elementwise_and_pools(dev):
         rb = ops.empty(300, Cc, device=dev)
         call("sv_relu_bwd", ptr(ad), ptr(bd), ptr(rb), 300 * Cc)
         dr = ops.empty(300, Cc, device=dev)
-        call("sv_dropout", ptr(ad), ptr(dr), 300 * Cc, 0.1, 123)
+        call("sv_dropout", ptr(ad), ptr(dr), 300 * Cc, 0.1, 123, None)
         rs = ops.empty(300, Cc, device=dev)
         call("sv_rowscale", ptr(ad), ptr(D(sc, dev)), ptr(rs), 300, Cc, 100)
         tr = ops.empty(Cc, 300, device=dev)

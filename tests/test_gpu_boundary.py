@@ -111,6 +111,9 @@ def test_two_threads_run_modules_concurrently(dev, storage):
             for a, b in zip(seq_nets[i], thr_nets[i]):
                 for (k, pa), pb in zip(a.named_parameters(), b.parameters()):
                     sc = float(pa.grad.abs().max()) + 1e-12
+                    if sc < 1e-7:      # analytically zero (conv bias in front of a train-mode BatchNorm): rounding noise only
+                        assert float(pb.grad.abs().max()) < 1e-7
+                        continue
                     assert float((pa.grad - pb.grad).abs().max()) <= (1e-3 if storage == "f32" else 5e-2) * sc, (i, k)
                 for (k, ba), bb in zip(a.named_buffers(), b.buffers()):     # running statistics and num_batches_tracked ticked 3 times each
                     assert torch.allclose(ba.float(), bb.float(), rtol=1e-3 if storage == "f32" else 2e-2, atol=1e-5), (i, k)
@@ -133,4 +136,91 @@ def test_evaluate_runs_in_eval_mode_and_restores_training(dev):
     assert all(n.training for n in nets)                                    # mode restored
     after = {k: v for n in nets for k, v in n.state_dict().items() if "running" in k or "num_batches" in k}
     assert all(torch.equal(before[k], after[k]) for k in before)            # no statistics update, no tick
-    assert torch.equal(a[2], b[2]) and float((a[0] - b[0]).abs()) == 0.0    # deterministic: no dropout / drop-path
+    assert torch.equal(a[2], b[2]) and float((a[0] - b[0]).abs()) <= 1e-5 * float(a[0].abs())   # no dropout / drop-path (loss atomics reorder)
+
+
+def test_golden_recipe_inside_the_product(dev):
+    """swinvox_amd.goldens rebuilds the golden network on the HIP modules (name-seeded fill identical to the oracle's, calibration
+    in exact-fp32 mode): the stored fp32 outputs of case_B1_V2 are reproduced - this is what bench.py's `iou_delta_vs_oracle` uses."""
+    import json
+    import os
+    import numpy as np
+    from swinvox_amd import goldens
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    o, p = O.Decoder(O.default_cfg()), Decoder(S.default_cfg())
+    O.seeded_weights_(o, seed=101)
+    goldens.seeded_fill_(p, 101)
+    assert all(torch.equal(a, b) for a, b in zip(o.state_dict().values(), p.state_dict().values()))
+    seed = json.load(open(os.path.join(gdir, "manifest.json")))["cases"]["B1_V2"]["seed"]
+    S.set_math("f32")
+    nets, x, gt = goldens.golden_case(dev, 1, 2, seed)
+    gold = np.load(os.path.join(gdir, "case_B1_V2.npz"))
+    with torch.no_grad():
+        f = nets[0](x)
+        raw, vol = nets[1](f)
+        refined = nets[3](nets[2](raw, vol)).cpu()
+    assert float((f.cpu() - torch.from_numpy(gold["features"])).abs().max()) < 1e-3 * float(np.abs(gold["features"]).max())
+    assert float((refined - torch.from_numpy(gold["refined"])).abs().max()) < 3e-3
+    iou, _ = harness.voxel_metrics(refined.to(dev), gt, S.default_cfg().TEST.VOXEL_THRESH)
+    assert np.abs(iou.cpu().numpy() - gold["iou"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_graph_replay_equals_the_eager_step(dev, storage):
+    """graph.GraphedStep: one forward + BCE + backward of all four modules captured into a hipGraph (three streams, ~1 400 launches)
+    and replayed.  With the stochastic layers off the replayed loss and gradients equal the eager ones; with them on every replay
+    draws new dropout / drop-path masks (device-side seed epoch) while forward and backward of one replay agree."""
+    from swinvox_amd.graph import GraphedStep
+    S.set_math("bf16" if storage == "bf16" else "f32")
+    if storage == "bf16":
+        S.set_storage("bf16")
+    try:
+        cfg = S.default_cfg()
+        nets = [Encoder(cfg), Decoder(cfg), Merger(cfg), Refiner(cfg)]
+        for i, n in enumerate(nets):
+            O.seeded_weights_(n, seed=30 + i)
+            n.to(dev).train()
+            n.stochastic = False
+        g = torch.Generator().manual_seed(5)
+        x = (0.5 * torch.randn(1, 2, 3, 224, 224, generator=g)).clamp(-1, 1).to(dev)
+        gt = (torch.rand(1, 32, 32, 32, generator=g) < 0.1).float().to(dev)
+        xs, gs = x.clone(), gt.clone()
+
+        def compute():
+            for n in nets:
+                for p in n.parameters():
+                    p.grad = None
+            raw, vol = nets[1](nets[0](xs))
+            merged = nets[2](raw, vol)
+            total = bce_with_logits(merged, gs) + bce_with_logits(nets[3](merged), gs)
+            total.backward()
+            return total.detach()
+
+        bn_before = {k: v.clone() for n in nets for k, v in n.state_dict().items() if "num_batches" in k}
+        want = compute().clone()
+        want_g = [p.grad.clone() for n in nets for p in n.parameters()]
+        step = GraphedStep(compute, static_inputs=[xs, gs], warmup=1)
+        got = step(x, gt).clone()
+        tol = 1e-5 if storage == "f32" else 2e-3
+        assert abs(float(got) - float(want)) <= tol * max(1.0, abs(float(want)))
+        worst = 0.0
+        for a, p in zip(want_g, [p for n in nets for p in n.parameters()]):
+            sc = float(a.abs().max())
+            if sc > 1e-7:
+                worst = max(worst, float((a - p.grad).abs().max()) / sc)
+        assert worst < (2e-3 if storage == "f32" else 0.15), worst       # atomics reorder sums; running BN stats moved between the runs
+        # a different batch through the same graph: the static inputs are overwritten, the loss follows
+        x2 = (0.5 * torch.randn(1, 2, 3, 224, 224, generator=g)).clamp(-1, 1).to(dev)
+        other = float(step(x2, gt))
+        assert abs(other - float(want)) > 1e-6
+        ticks = {k: v for n in nets for k, v in n.state_dict().items() if "num_batches" in k}
+        assert all(int(ticks[k]) == int(bn_before[k]) + 2 + step.replays for k in ticks)   # eager + warm-up + capture run nothing twice
+        # stochastic layers on: replays differ from each other (fresh masks), stay finite
+        for n in nets:
+            n.stochastic = True
+        step2 = GraphedStep(compute, static_inputs=[xs, gs], warmup=1)
+        l1 = float(step2(x, gt)); g1 = nets[0].fusion_layer[0].weight.grad.clone()
+        l2 = float(step2(x, gt)); g2 = nets[0].fusion_layer[0].weight.grad.clone()
+        assert l1 != l2 and not torch.equal(g1, g2) and bool(torch.isfinite(g2).all())
+    finally:
+        S.set_math("f32")

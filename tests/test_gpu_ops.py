@@ -251,12 +251,12 @@ def test_ln_image(dev):
     xd = x.detach().reshape(I, L).to(dev)
     out, mr = ops.empty(I, L, device=dev), ops.empty(2 * I, device=dev)
     ws = ops.empty(int(hip.load().sv_ln_image_workspace_floats(I, L)), device=dev)
-    call("sv_ln_image_fwd", ptr(xd), ptr(wt), ptr(bt), ptr(out), ptr(mr), ptr(ws), I, L, 1e-5, 0.0, 0)
+    call("sv_ln_image_fwd", ptr(xd), ptr(wt), ptr(bt), ptr(out), ptr(mr), ptr(ws), I, L, 1e-5, 0.0, 0, None)
     assert rel(out, y.permute(0, 2, 3, 1).reshape(I, L)) < TOL
     dx, dw, db = ops.empty(I, L, device=dev), ops.zeros(L, device=dev), ops.zeros(L, device=dev)
     sums = torch.empty(2 * I, dtype=torch.float64, device=dev)
     dyd = dy.permute(0, 2, 3, 1).reshape(I, L).contiguous().to(dev)
-    call("sv_ln_image_bwd", ptr(dyd), ptr(xd), ptr(wt), ptr(mr), ptr(dx), ptr(dw), ptr(db), ptr(sums), I, L, 0.0, 0)
+    call("sv_ln_image_bwd", ptr(dyd), ptr(xd), ptr(wt), ptr(mr), ptr(dx), ptr(dw), ptr(db), ptr(sums), I, L, 0.0, 0, None)
     assert rel(dx, x.grad.reshape(I, L)) < TOL
     assert rel(dw, w.grad.permute(1, 2, 0).reshape(L)) < TOL and rel(db, b.grad.permute(1, 2, 0).reshape(L)) < TOL
 
@@ -481,9 +481,18 @@ def test_merge_bce_iou_dropout(dev):
     n = 1 << 20
     ones = torch.ones(n, device=dev)
     y1, y2 = ops.empty(n, device=dev), ops.empty(n, device=dev)
-    call("sv_dropout", ptr(ones), ptr(y1), n, 0.1, 1234)
-    call("sv_dropout", ptr(ones), ptr(y2), n, 0.1, 1234)
+    call("sv_dropout", ptr(ones), ptr(y1), n, 0.1, 1234, None)
+    call("sv_dropout", ptr(ones), ptr(y2), n, 0.1, 1234, None)
     assert torch.equal(y1, y2)
+    # device-side seed epoch (hipGraph replays freeze the scalar seed): same word -> same mask, another word -> another mask
+    ep = torch.tensor([3], dtype=torch.int32, device=dev)
+    y3, y4 = ops.empty(n, device=dev), ops.empty(n, device=dev)
+    call("sv_dropout", ptr(ones), ptr(y3), n, 0.1, 1234, ptr(ep))
+    call("sv_dropout", ptr(ones), ptr(y4), n, 0.1, 1234, ptr(ep))
+    assert torch.equal(y3, y4) and not torch.equal(y3, y1)
+    ep.add_(1)
+    call("sv_dropout", ptr(ones), ptr(y4), n, 0.1, 1234, ptr(ep))
+    assert not torch.equal(y3, y4) and abs(float((y4 == 0).float().mean()) - 0.1) < 5e-3
     frac = float((y1 == 0).float().mean())
     assert abs(frac - 0.1) < 5e-3 and abs(float(y1.max()) - 1 / 0.9) < 1e-6
 
