@@ -178,7 +178,7 @@ class ConvSpec:
         if kind == "f" and dt == torch.float32 and not self.transposed and self.taps == 1 and self.cin_mem == self.cin:
             return w  # Linear / 1x1 conv in fp32: the native layout already is the packed layout
         cache = _CTX.packs
-        if cache is not None:
+        if cache is not None and isinstance(w, torch.nn.Parameter):   # temporaries (re-indexed copies) would add an entry per step
             return cache.get(self, w, kind)
         return pack_one(self, w, kind)
 
