@@ -228,6 +228,25 @@ int sv_decoder_head_bwd(const void* draw12, const void* dvol, const void* x8, co
 int sv_merge_views_fwd(const void* wlogit, const void* vol, void* out, int B, int V, int S, int act_dtype, void* stream);  /* merger.py:91-104 */
 int sv_merge_views_bwd(const void* wlogit, const void* vol, const void* out, const void* dout, void* dwlogit, void* dvol,
                        int B, int V, int S, int act_dtype, void* stream);
+/* Fused Swin MLP branch  x2 = x1 + s * fc2(GELU(fc1(LayerNorm(x1))))  (timm Mlp + norm2 + DropPath of a SwinTransformerBlock behind
+ * models/swin_transformer.py:78) with no hidden activation in HBM: bf16 activations / bf16 MFMA only, C in {96, 128, 192}
+ * (sv_swin_mlp_supported).  x1, x2, dx1, dx2: [M, C] bf16 token rows; w1 [4C, C], b1 [4C], w2 [C, 4C], b2 [C], ln_g / ln_b [C]: fp32
+ * parameters in their native layouts; row_scale (may be NULL): one drop-path factor per rows_per_scale consecutive rows.
+ *  sv_swin_mlp_pack:  w1, w2 -> `packs` (16 C^2 bf16 elements): four images in MFMA fragment order, read by _fwd and _bwd.
+ *  sv_swin_mlp_fwd:   x2 from x1.
+ *  sv_swin_mlp_bwd:   dx1 = dx2 + d(branch)/dx1, recomputing LayerNorm and the pre-activation; dgamma / dbeta += LayerNorm gradients.
+ *  sv_swin_mlp_wgrad: dw1, db1, dw2, db2 += weight gradients, recomputing the hidden activation per hidden-unit chunk;
+ *                     w1_rows = bf16 [4C][C] (fc1.weight), w2t_rows = bf16 [4C][C] (fc2.weight transposed).                          */
+int sv_swin_mlp_supported(int C);
+int sv_swin_mlp_pack(const float* w1, const float* w2, void* packs, int C, void* stream);
+int sv_swin_mlp_fwd(const void* x1, void* x2, const float* ln_g, const float* ln_b, const void* packs, const float* b1, const float* b2,
+                    const float* row_scale, int rows_per_scale, long long M, int C, float eps, void* stream);
+int sv_swin_mlp_bwd(const void* x1, const void* dx2, void* dx1, const float* ln_g, const float* ln_b, const void* packs, const float* b1,
+                    const float* row_scale, int rows_per_scale, float* dgamma, float* dbeta, long long M, int C, float eps, void* stream);
+int sv_swin_mlp_wgrad(const void* x1, const void* dx2, const float* ln_g, const float* ln_b, const void* w1_rows, const void* w2t_rows,
+                      const float* b1, const float* row_scale, int rows_per_scale, float* dw1, float* db1, float* dw2, float* db2,
+                      long long M, int C, float eps, void* stream);
+
 /* harness-side kernels on fp32 module outputs */
 int sv_mean_views(const float* vol, float* out, int B, int V, int S, void* stream);                      /* core/train.py:246 */
 int sv_bce_logits(const float* x, const float* t, long long n, float* loss_accum, float* dx, const float* gscale_dev, void* stream); /* core/train.py:165,249,255 */

@@ -1,0 +1,633 @@
+// Fused Swin MLP branch for gfx950:  x2 = x1 + s * fc2(GELU(fc1(LayerNorm(x1))))   (timm Mlp + norm2 + DropPath behind
+// reference models/swin_transformer.py:78), forward, data gradient and weight gradients, with NO hidden activation in HBM.
+//
+// Unfused, a stage-0 block moves 7.5 GB per step for this branch (the 4C-wide hidden tensor is written twice in the forward -
+// pre-activation and GELU output - and read / written four more times in the backward) through kernels that are bound by the
+// HBM write stream.  Here the hidden tile never leaves the CU:
+//   swin_mlp_fwd_kernel   one wave owns 32 tokens.  H^T chunk [32 hidden x 32 tokens] = W1 chunk . LN(x)^T on MFMA 32x32x16, bias +
+//                         GELU on the accumulator, and the accumulator is fed straight back as the B operand of the second product
+//                         Y^T += W2 chunk . H^T (an accumulator tile is a valid B fragment when the other operand's k order is permuted to
+//                         match - cdna_hip_programming.md "An accumulator tile as the next MFMA's operand").  Weight chunks stream from L2
+//                         through a double-buffered LDS ring in FRAGMENT ORDER (sv_swin_mlp_pack), so every A fragment is one
+//                         conflict-free ds_read_b128.  Reads x1, writes x2: 4 bytes per element instead of 26.
+//   swin_mlp_bwd_kernel   same skeleton, recomputes LN and the pre-activation, dH^T = (W2^T chunk . dy^T) * GELU'(hpre), dLN^T += W1^T chunk . dH^T,
+//                         then the LayerNorm backward and the residual add on the accumulator; dgamma / dbeta by DPP row reductions.
+//   swin_mlp_wgrad_kernel a workgroup owns a slice of the hidden units (one 16/32-wide chunk per wave) and walks a range of tokens: the
+//                         x / dy tiles go to LDS once per 128 tokens and serve every wave; H and dH are recomputed for the wave's chunk
+//                         (MFMA 16x16x32, tokens on the accumulator rows) and contracted over the tokens with the transposed tiles read by
+//                         ds_read_b64_tr_b16: dW2 += dy^T . H, dW1^T += LN(x)^T . dH.  Accumulators stay in registers for the whole range.
+// bf16 storage + bf16 MFMA only (the exact-fp32 parity mode keeps the unfused chain); C = 96, 128, 192 (Swin-T stages 0-1, Swin-B stage 0).
+#include "common.h"
+
+namespace sv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+
+struct MlpArgs {
+  const __bf16* x1; const __bf16* dx2; __bf16* out;
+  const float* ln_g; const float* ln_b; float eps;
+  const __bf16* packs;                 // W1F | W2F | W2TF | W1TF, 4C*C elements each (sv_swin_mlp_pack)
+  const float* b1; const float* b2;
+  const float* row_scale; int rows_per_scale;
+  float* dgamma; float* dbeta;
+  long long M; int ntiles;
+};
+
+// ---- weight packs in MFMA fragment order ------------------------------------------------------------------------------------
+// chunk = 32 hidden units.  "row-k" images (A = [32 hidden rows][k = c]):       [chunk][f = c/16][lane][8]   lane = (r, h): hid = 32 chunk + r, c = 16 f + 8 h + j
+//                           "k-perm" images (A = [32 c rows][k = hidden, permuted]): [chunk][blk = c/32][s][lane][8] lane = (r, h): c = 32 blk + r,
+//                           hid = 32 chunk + 16 s + 8 (j >> 2) + 4 h + (j & 3)  - the k order in which a 32x32 accumulator tile is a B fragment.
+__global__ __launch_bounds__(256) void swin_mlp_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, __bf16* __restrict__ packs, int C) {
+  const int HID = 4 * C;
+  const long long n = (long long)HID * C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < 4 * n; idx += (long long)gridDim.x * 256) {
+    const int img = (int)(idx / n);
+    const int e = (int)(idx % n);
+    const int chunk = e / (32 * C), rem = e % (32 * C);
+    const int lane = (rem % 512) / 8, j = rem % 8, r = lane & 31, h = lane >> 5;
+    float v;
+    if (img == 0 || img == 2) {
+      const int f = rem / 512;
+      const int hid = 32 * chunk + r, c = 16 * f + 8 * h + j;
+      v = img == 0 ? w1[(size_t)hid * C + c] : w2[(size_t)c * HID + hid];
+    } else {
+      const int blk = rem / 1024, s = (rem % 1024) / 512;
+      const int c = 32 * blk + r, hid = 32 * chunk + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+      v = img == 1 ? w2[(size_t)c * HID + hid] : w1[(size_t)hid * C + c];
+    }
+    packs[idx] = (__bf16)v;
+  }
+}
+
+// GELU and its derivative from one erf / one exp (fast forms of common.h: the operands carry bf16 precision)
+__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float ex = __expf(-ax * ax);                       // = exp(-x^2 / 2)
+  const float erfv = copysignf(1.f - poly * ex, x);
+  const float cdf = 0.5f * (1.f + erfv);
+  g = x * cdf;
+  dg = cdf + x * 0.39894228040143267794f * ex;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {   // registers 8s .. 8s+7 -> one bf16 fragment
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * s + j];
+  return r;
+}
+
+// sum over the 32 lanes of each wave half (lanes 0-31 -> lane 31, lanes 32-63 -> lane 63) on the VALU (DPP row shifts + row broadcast)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_shift(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float half_wave_total(float v) {
+  v += dpp_shift<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_shift<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_shift<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_shift<0x118, 0xf>(v);   // row_shr:8  -> lane 15 of every 16-lane row holds the row total
+  v += dpp_shift<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold the totals of lanes 0-31 / 32-63
+  return v;
+}
+
+// One 64-hidden-unit weight stage (NIMG images, 64 C elements each) HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4): a wave
+// instruction moves 1 KB, lane l's 16 bytes landing at (wave-uniform LDS base) + 16 l - exactly the fragment order of the packs, so
+// the copy needs no staging registers and runs under the MFMAs of the previous stage.  Completion: the vmcnt(0) that
+// __syncthreads() carries while a DMA is in flight.
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+template <int C, int NW, int NIMG>
+__device__ __forceinline__ void stage_dma(const __bf16* const (&img)[NIMG], int pair, __bf16* stage, int wave, int lane) {
+  constexpr int PIECES = NIMG * 8 * C / 64;          // 1-KB pieces per stage (8 C / 64 per image)
+#pragma unroll
+  for (int pc = wave; pc < PIECES; pc += NW) {
+    const int im = pc / (8 * C / 64), o = pc % (8 * C / 64);
+    const __bf16* src = img[im] + (size_t)pair * 64 * C + o * 512 + lane * 8;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(stage + (size_t)pc * 512), 16, 0, 0);
+  }
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------------------
+template <int C, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void swin_mlp_fwd_kernel(const MlpArgs p) {
+  constexpr int NF = C / 16, NB = C / 32, HID = 4 * C, NPAIR = HID / 64, NT = NW * 64;
+  constexpr int STAGE = 2 * 64 * C;                      // bf16 elements: W1F pair | W2F pair
+  __shared__ __attribute__((aligned(16))) __bf16 wbuf[2 * STAGE];
+  __shared__ float sb1[HID];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const long long HC = (long long)HID * C;
+  const __bf16* const imgs[2] = {p.packs, p.packs + HC};
+  for (int i = tid; i < HID; i += NT) sb1[i] = p.b1[i];
+
+  const long long tok = (long long)blockIdx.x * (NW * 32) + wave * 32 + r;
+  const bool valid = tok < p.M;
+  // ---- LayerNorm of the wave's 32 token rows, straight into the B fragments of the first product (lane (r, h): 8 consecutive channels)
+  bf16x8 xn[NF];
+  {
+    float xv[NF][8];
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      bf16x8 raw = VecN<__bf16, 8>::zero();
+      if (valid) raw = *reinterpret_cast<const bf16x8*>(p.x1 + tok * C + 16 * f + 8 * h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { xv[f][j] = (float)raw[j]; s += xv[f][j]; }
+    }
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = xv[f][j] - mean; q += d * d; }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q * (1.f / C) + p.eps);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int c0 = 16 * f + 8 * h;
+      const float4 g0 = *reinterpret_cast<const float4*>(p.ln_g + c0), g1 = *reinterpret_cast<const float4*>(p.ln_g + c0 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(p.ln_b + c0), b1v = *reinterpret_cast<const float4*>(p.ln_b + c0 + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xn[f][j] = (__bf16)((xv[f][j] - mean) * rstd * gg[j] + bb[j]);
+    }
+  }
+
+  f32x16 acc2[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[b][i] = 0.f;
+
+  stage_dma<C, NW, 2>(imgs, 0, wbuf, wave, lane);
+  for (int pr = 0; pr < NPAIR; ++pr) {
+    const __bf16* st = wbuf + (pr & 1) * STAGE;
+    __syncthreads();                                     // stage pr has landed; everybody is done with the other buffer
+    if (pr + 1 < NPAIR) stage_dma<C, NW, 2>(imgs, pr + 1, wbuf + ((pr + 1) & 1) * STAGE, wave, lane);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 acc1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+      const __bf16* w1f = st + sub * 32 * C;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(w1f + f * 512 + lane * 8);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xn[f], acc1, 0, 0, 0);      // H^T chunk: rows = hidden, columns = tokens
+      }
+      const int hid0 = (2 * pr + sub) * 32;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float v = acc1[i] + sb1[hid0 + (i & 3) + 8 * (i >> 2) + 4 * h];
+        acc1[i] = 0.5f * v * (1.f + erf_fast(v * 0.70710678118654752440f));
+      }
+      const bf16x8 hb0 = pack8(acc1, 0), hb1 = pack8(acc1, 1);
+      const __bf16* w2f = st + 64 * C + sub * 32 * C;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(w2f + (b * 2 + 0) * 512 + lane * 8);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(w2f + (b * 2 + 1) * 512 + lane * 8);
+        acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, hb0, acc2[b], 0, 0, 0);  // Y^T: rows = output channels, columns = tokens
+        acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hb1, acc2[b], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: + bias, drop-path scale, + residual; lane (r, h) owns channels 32 b + 8 g + 4 h .. + 3 of token r
+  if (valid) {
+    const float sc = p.row_scale ? p.row_scale[tok / p.rows_per_scale] : 1.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = 32 * b + 8 * g + 4 * h;
+        const float4 bi = *reinterpret_cast<const float4*>(p.b2 + c0);
+        const bf16x4 res = *reinterpret_cast<const bf16x4*>(p.x1 + tok * C + c0);
+        bf16x4 o;
+        o[0] = (__bf16)((float)res[0] + sc * (acc2[b][4 * g + 0] + bi.x));
+        o[1] = (__bf16)((float)res[1] + sc * (acc2[b][4 * g + 1] + bi.y));
+        o[2] = (__bf16)((float)res[2] + sc * (acc2[b][4 * g + 2] + bi.z));
+        o[3] = (__bf16)((float)res[3] + sc * (acc2[b][4 * g + 3] + bi.w));
+        *reinterpret_cast<bf16x4*>(p.out + tok * C + c0) = o;
+      }
+  }
+}
+
+// ---- data gradient ------------------------------------------------------------------------------------------------------
+// dx1 = dx2 + LayerNormBackward( (s * dx2 . W2) * GELU'(hpre) . W1 ),  dgamma / dbeta of the LayerNorm accumulated per workgroup
+template <int C, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void swin_mlp_bwd_kernel(const MlpArgs p) {
+  constexpr int NF = C / 16, NB = C / 32, HID = 4 * C, NPAIR = HID / 64, NT = NW * 64;
+  constexpr int STAGE = 3 * 64 * C;                      // W1F pair | W2TF pair | W1TF pair
+  __shared__ __attribute__((aligned(16))) __bf16 wbuf[2 * STAGE];
+  __shared__ float sb1[HID];
+  __shared__ float sdg[C], sdb[C];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const long long HC = (long long)HID * C;
+  const __bf16* const imgs[3] = {p.packs, p.packs + 2 * HC, p.packs + 3 * HC};
+  for (int i = tid; i < HID; i += NT) sb1[i] = p.b1[i];
+  for (int i = tid; i < C; i += NT) { sdg[i] = 0.f; sdb[i] = 0.f; }
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const long long tok = (long long)tile * (NW * 32) + wave * 32 + r;
+    const bool valid = tok < p.M;
+    const float sc = (valid && p.row_scale) ? p.row_scale[tok / p.rows_per_scale] : 1.f;
+    bf16x8 xn[NF], dyb[NF];
+    float mean, rstd;
+    {
+      float xv[NF][8];
+      float s = 0.f;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        bf16x8 raw = VecN<__bf16, 8>::zero(), dr = VecN<__bf16, 8>::zero();
+        if (valid) {
+          raw = *reinterpret_cast<const bf16x8*>(p.x1 + tok * C + 16 * f + 8 * h);
+          dr = *reinterpret_cast<const bf16x8*>(p.dx2 + tok * C + 16 * f + 8 * h);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xv[f][j] = (float)raw[j]; s += xv[f][j]; dyb[f][j] = (__bf16)(sc * (float)dr[j]); }
+      }
+      s += __shfl_xor(s, 32, 64);
+      mean = s * (1.f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = xv[f][j] - mean; q += d * d; }
+      q += __shfl_xor(q, 32, 64);
+      rstd = rsqrtf(q * (1.f / C) + p.eps);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int c0 = 16 * f + 8 * h;
+        const float4 g0 = *reinterpret_cast<const float4*>(p.ln_g + c0), g1 = *reinterpret_cast<const float4*>(p.ln_g + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.ln_b + c0), b1v = *reinterpret_cast<const float4*>(p.ln_b + c0 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xn[f][j] = (__bf16)((xv[f][j] - mean) * rstd * gg[j] + bb[j]);
+      }
+    }
+    f32x16 acc3[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc3[b][i] = 0.f;
+
+    __syncthreads();                                     // previous tile: every wave has left its last stage
+    stage_dma<C, NW, 3>(imgs, 0, wbuf, wave, lane);
+    for (int pr = 0; pr < NPAIR; ++pr) {
+      const __bf16* st = wbuf + (pr & 1) * STAGE;
+      __syncthreads();
+      if (pr + 1 < NPAIR) stage_dma<C, NW, 3>(imgs, pr + 1, wbuf + ((pr + 1) & 1) * STAGE, wave, lane);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        f32x16 acc1, accd;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc1[i] = 0.f; accd[i] = 0.f; }
+        const __bf16* w1f = st + sub * 32 * C;
+        const __bf16* w2tf = st + 64 * C + sub * 32 * C;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(w1f + f * 512 + lane * 8);
+          const bf16x8 at = *reinterpret_cast<const bf16x8*>(w2tf + f * 512 + lane * 8);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xn[f], acc1, 0, 0, 0);     // pre-activation^T (recomputed)
+          accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, dyb[f], accd, 0, 0, 0);   // (dy . W2)^T
+        }
+        const int hid0 = (2 * pr + sub) * 32;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float g, dg;
+          gelu_both(acc1[i] + sb1[hid0 + (i & 3) + 8 * (i >> 2) + 4 * h], g, dg);
+          accd[i] *= dg;
+        }
+        const bf16x8 d0 = pack8(accd, 0), d1 = pack8(accd, 1);
+        const __bf16* w1tf = st + 128 * C + sub * 32 * C;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(w1tf + (b * 2 + 0) * 512 + lane * 8);
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(w1tf + (b * 2 + 1) * 512 + lane * 8);
+          acc3[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, d0, acc3[b], 0, 0, 0);  // dLN^T: rows = channels, columns = tokens
+          acc3[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, d1, acc3[b], 0, 0, 0);
+        }
+      }
+    }
+    // ---- LayerNorm backward on the accumulator (lane (r, h): channels 32 b + 8 g + 4 h + k of token r)
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = 32 * b + 8 * g + 4 * h;
+        bf16x4 xr = V4<__bf16>::zero();
+        if (valid) xr = *reinterpret_cast<const bf16x4*>(p.x1 + tok * C + c0);
+        const float4 gm = *reinterpret_cast<const float4*>(p.ln_g + c0);
+        const float gv[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xh = valid ? ((float)xr[k] - mean) * rstd : 0.f;
+          const float d = valid ? acc3[b][4 * g + k] : 0.f;
+          const float gg = d * gv[k];
+          s1 += gg; s2 += gg * xh;
+          // dgamma / dbeta: totals over the 32 tokens of this lane half arrive in lanes 31 and 63
+          const float tb = half_wave_total(d), tg = half_wave_total(d * xh);
+          if (r == 31) { atomicAdd(&sdb[c0 + k], tb); atomicAdd(&sdg[c0 + k], tg); }
+        }
+      }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    s1 *= (1.f / C); s2 *= (1.f / C);
+    if (valid) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = 32 * b + 8 * g + 4 * h;
+          const bf16x4 xr = *reinterpret_cast<const bf16x4*>(p.x1 + tok * C + c0);
+          const bf16x4 dr = *reinterpret_cast<const bf16x4*>(p.dx2 + tok * C + c0);
+          const float4 gm = *reinterpret_cast<const float4*>(p.ln_g + c0);
+          const float gv[4] = {gm.x, gm.y, gm.z, gm.w};
+          bf16x4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float xh = ((float)xr[k] - mean) * rstd;
+            o[k] = (__bf16)((float)dr[k] + rstd * (acc3[b][4 * g + k] * gv[k] - s1 - xh * s2));
+          }
+          *reinterpret_cast<bf16x4*>(p.out + tok * C + c0) = o;
+        }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < C; i += NT) { atomicAdd(p.dgamma + i, sdg[i]); atomicAdd(p.dbeta + i, sdb[i]); }
+}
+
+// ---- weight gradients --------------------------------------------------------------------------------------------------------
+struct MlpWArgs {
+  const __bf16* x1; const __bf16* dx2;
+  const float* ln_g; const float* ln_b; float eps;
+  const __bf16* w1r;   // [4C][C]  fc1 weight rows (forward pack of fc1)
+  const __bf16* w2tr;  // [4C][C]  fc2 weight transposed (data-gradient pack of fc2)
+  const float* b1; const float* row_scale; int rows_per_scale;
+  float* dw1; float* db1; float* dw2; float* db2;     // native layouts [4C][C], [4C], [C][4C], [C]
+  long long M; int tok_per_split; int HG;
+};
+
+template <int C, int NW, int HCW>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void swin_mlp_wgrad_kernel(const MlpWArgs p) {
+  constexpr int NF = C / 32, NCB = C / 16, NHB = HCW / 16, HID = 4 * C, NT = NW * 64, TT = 128, LD = C + 8;
+  __shared__ __attribute__((aligned(16))) __bf16 xs[TT * LD];    // LayerNorm(x1) tile  [token][channel]
+  __shared__ __attribute__((aligned(16))) __bf16 ds[TT * LD];    // s * dx2 tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4, q = lr >> 2, pp = lr & 3;
+  const int hg = blockIdx.x % p.HG, split = blockIdx.x / p.HG;
+  const int h0 = (hg * NW + wave) * HCW;                         // first hidden unit of this wave
+  const long long t_begin = (long long)split * p.tok_per_split;
+  long long t_end = t_begin + p.tok_per_split;
+  if (t_end > p.M) t_end = p.M;
+
+  // per-wave constant B fragments: W1 rows / W2^T rows of the wave's hidden units (k = channels, 8 consecutive per lane)
+  bf16x8 w1b[NHB][NF], w2b[NHB][NF];
+  float b1v[NHB];
+#pragma unroll
+  for (int hb = 0; hb < NHB; ++hb) {
+    const int hid = h0 + 16 * hb + lr;
+    b1v[hb] = p.b1[hid];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      w1b[hb][f] = *reinterpret_cast<const bf16x8*>(p.w1r + (size_t)hid * C + 32 * f + 8 * lg);
+      w2b[hb][f] = *reinterpret_cast<const bf16x8*>(p.w2tr + (size_t)hid * C + 32 * f + 8 * lg);
+    }
+  }
+  f32x4 G2[NCB][NHB], G1[NCB][NHB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int hb = 0; hb < NHB; ++hb) { G2[cb][hb] = (f32x4){0.f, 0.f, 0.f, 0.f}; G1[cb][hb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  float db1acc[NHB];
+#pragma unroll
+  for (int hb = 0; hb < NHB; ++hb) db1acc[hb] = 0.f;
+  float db2acc = 0.f;
+
+  constexpr int UPR = C / 8;                 // 16-byte units per token row
+  for (long long t0 = t_begin; t0 < t_end; t0 += TT) {
+    __syncthreads();                         // the previous tile has been consumed
+    // ---- tile load: raw x1 and s * dx2 rows (contiguous in HBM), 16 bytes per unit
+    for (int u = tid; u < TT * UPR; u += NT) {
+      const int row = u / UPR, cu = u % UPR;
+      const long long tok = t0 + row;
+      bf16x8 xv = VecN<__bf16, 8>::zero(), dv = VecN<__bf16, 8>::zero();
+      if (tok < t_end) {
+        xv = *reinterpret_cast<const bf16x8*>(p.x1 + tok * C + cu * 8);
+        dv = *reinterpret_cast<const bf16x8*>(p.dx2 + tok * C + cu * 8);
+        if (p.row_scale) {
+          const float sc = p.row_scale[tok / p.rows_per_scale];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dv[j] = (__bf16)(sc * (float)dv[j]);
+        }
+      }
+      *reinterpret_cast<bf16x8*>(xs + row * LD + cu * 8) = xv;
+      *reinterpret_cast<bf16x8*>(ds + row * LD + cu * 8) = dv;
+    }
+    __syncthreads();
+    // ---- LayerNorm in place (one thread per token row); rows past the end stay zero
+    if (tid < TT) {
+      __bf16* rowp = xs + tid * LD;
+      const bool live = t0 + tid < t_end;
+      float s = 0.f;
+      for (int c = 0; c < C; c += 8) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(rowp + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)v[j];
+      }
+      const float mean = s * (1.f / C);
+      float qv = 0.f;
+      for (int c = 0; c < C; c += 8) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(rowp + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - mean; qv += d * d; }
+      }
+      const float rstd = rsqrtf(qv * (1.f / C) + p.eps);
+      for (int c = 0; c < C; c += 8) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(rowp + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = live ? (__bf16)(((float)v[j] - mean) * rstd * p.ln_g[c + j] + p.ln_b[c + j]) : (__bf16)0.f;
+        *reinterpret_cast<bf16x8*>(rowp + c) = v;
+      }
+    } else if (hg == 0 && tid >= TT && tid < TT + C) {     // bias gradient of fc2: column sums of the dy tile
+      const int c = tid - TT;
+      float s = 0.f;
+#pragma unroll 8
+      for (int row = 0; row < TT; ++row) s += (float)ds[row * LD + c];
+      db2acc += s;
+    }
+    __syncthreads();
+    // ---- the wave's hidden chunk against the four 32-token sub-tiles
+#pragma unroll 1
+    for (int sub = 0; sub < TT / 32; ++sub) {
+      f32x4 Hh[2][NHB], Dh[2][NHB];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        bf16x8 xa[NF], da[NF];
+        const int row = 32 * sub + 16 * tb + lr;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          xa[f] = *reinterpret_cast<const bf16x8*>(xs + row * LD + 32 * f + 8 * lg);
+          da[f] = *reinterpret_cast<const bf16x8*>(ds + row * LD + 32 * f + 8 * lg);
+        }
+#pragma unroll
+        for (int hb = 0; hb < NHB; ++hb) {
+          f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, d = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[f], w1b[hb][f], a, 0, 0, 0);   // rows = tokens, columns = hidden units
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[f], w2b[hb][f], d, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float g, dg;
+            gelu_both(a[i] + b1v[hb], g, dg);
+            a[i] = g;
+            d[i] *= dg;
+            db1acc[hb] += d[i];
+          }
+          Hh[tb][hb] = a; Dh[tb][hb] = d;
+        }
+      }
+      // B fragments of the token contraction: the stacked accumulator blocks (k order {4 lg + i} U {16 + 4 lg + i})
+      bf16x8 hB[NHB], dB[NHB];
+#pragma unroll
+      for (int hb = 0; hb < NHB; ++hb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          hB[hb][i] = (__bf16)Hh[0][hb][i]; hB[hb][4 + i] = (__bf16)Hh[1][hb][i];
+          dB[hb][i] = (__bf16)Dh[0][hb][i]; dB[hb][4 + i] = (__bf16)Dh[1][hb][i];
+        }
+      // A fragments: transposed tiles (rows = channels, k = tokens in the same order) by ds_read_b64_tr_b16
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const __bf16* sx = xs + (32 * sub + 4 * lg + q) * LD + 16 * cb + 4 * pp;
+        const __bf16* sd = ds + (32 * sub + 4 * lg + q) * LD + 16 * cb + 4 * pp;
+        const bf16x4 xlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(sx));
+        const bf16x4 xhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(sx + 16 * LD));
+        const bf16x4 dlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(sd));
+        const bf16x4 dhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(sd + 16 * LD));
+        const bf16x8 xT = __builtin_shufflevector(xlo, xhi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 dT = __builtin_shufflevector(dlo, dhi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int hb = 0; hb < NHB; ++hb) {
+          G2[cb][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT, hB[hb], G2[cb][hb], 0, 0, 0);   // dW2[c][hid]
+          G1[cb][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xT, dB[hb], G1[cb][hb], 0, 0, 0);   // dW1[hid][c], held transposed
+        }
+      }
+    }
+  }
+  // ---- write out (accumulator: row = channel 16 cb + 4 lg + i, column = hidden unit h0 + 16 hb + lr)
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int hb = 0; hb < NHB; ++hb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 16 * cb + 4 * lg + i, hid = h0 + 16 * hb + lr;
+        atomicAdd(p.dw2 + (size_t)c * HID + hid, G2[cb][hb][i]);
+        atomicAdd(p.dw1 + (size_t)hid * C + c, G1[cb][hb][i]);
+      }
+#pragma unroll
+  for (int hb = 0; hb < NHB; ++hb) {
+    float v = db1acc[hb];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lg == 0) atomicAdd(p.db1 + h0 + 16 * hb + lr, v);
+  }
+  if (hg == 0 && tid >= TT && tid < TT + C) atomicAdd(p.db2 + (tid - TT), db2acc);
+}
+
+static inline bool mlp_supported(int C) { return C == 96 || C == 128 || C == 192; }
+
+}  // namespace sv
+
+using namespace sv;
+#define STREAM static_cast<hipStream_t>(stream)
+
+extern "C" int sv_swin_mlp_supported(int C) { return mlp_supported(C) ? 1 : 0; }
+
+extern "C" int sv_swin_mlp_pack(const float* w1, const float* w2, void* packs, int C, void* stream) {
+  SV_REQUIRE(w1 && w2 && packs && mlp_supported(C), "swin_mlp_pack: bad arguments (C=%d)", C);
+  const long long total = 16ll * C * C;
+  hipLaunchKernelGGL(swin_mlp_pack_kernel, dim3(cdiv(total, 256 * 4)), dim3(256), 0, STREAM, w1, w2, static_cast<__bf16*>(packs), C);
+  return check_launch("sv_swin_mlp_pack");
+}
+
+static int mlp_check(const void* x1, const void* out, const float* g, const float* b, const void* packs, long long M, int C, int rps) {
+  SV_REQUIRE(x1 && out && g && b && packs && M > 0 && M < (1ll << 31) && mlp_supported(C), "swin_mlp: bad arguments (M=%lld C=%d)", M, C);
+  SV_REQUIRE((((uintptr_t)x1 | (uintptr_t)out | (uintptr_t)packs) & 15) == 0 && (((uintptr_t)g | (uintptr_t)b) & 15) == 0, "swin_mlp: operands must be 16-byte aligned");
+  SV_REQUIRE(rps > 0, "swin_mlp: rows_per_scale must be positive");
+  return SV_OK;
+}
+
+extern "C" int sv_swin_mlp_fwd(const void* x1, void* x2, const float* ln_g, const float* ln_b, const void* packs, const float* b1,
+                               const float* b2, const float* row_scale, int rows_per_scale, long long M, int C, float eps, void* stream) {
+  if (int rc = mlp_check(x1, x2, ln_g, ln_b, packs, M, C, rows_per_scale)) return rc;
+  SV_REQUIRE(b1 && b2 && (((uintptr_t)b2) & 15) == 0, "swin_mlp_fwd: biases required (16-byte aligned)");
+  MlpArgs a{};
+  a.x1 = static_cast<const __bf16*>(x1); a.out = static_cast<__bf16*>(x2); a.ln_g = ln_g; a.ln_b = ln_b; a.eps = eps;
+  a.packs = static_cast<const __bf16*>(packs); a.b1 = b1; a.b2 = b2; a.row_scale = row_scale; a.rows_per_scale = rows_per_scale; a.M = M;
+#define SV_MLP_FWD(CC, NW) hipLaunchKernelGGL((swin_mlp_fwd_kernel<CC, NW>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), 0, STREAM, a)
+  if (C == 96) SV_MLP_FWD(96, 8);
+  else if (C == 128) SV_MLP_FWD(128, 8);
+  else SV_MLP_FWD(192, 4);
+#undef SV_MLP_FWD
+  return check_launch("sv_swin_mlp_fwd");
+}
+
+extern "C" int sv_swin_mlp_bwd(const void* x1, const void* dx2, void* dx1, const float* ln_g, const float* ln_b, const void* packs,
+                               const float* b1, const float* row_scale, int rows_per_scale, float* dgamma, float* dbeta, long long M, int C,
+                               float eps, void* stream) {
+  if (int rc = mlp_check(x1, dx1, ln_g, ln_b, packs, M, C, rows_per_scale)) return rc;
+  SV_REQUIRE(dx2 && b1 && dgamma && dbeta && (((uintptr_t)dx2) & 15) == 0, "swin_mlp_bwd: bad arguments");
+  MlpArgs a{};
+  a.x1 = static_cast<const __bf16*>(x1); a.dx2 = static_cast<const __bf16*>(dx2); a.out = static_cast<__bf16*>(dx1);
+  a.ln_g = ln_g; a.ln_b = ln_b; a.eps = eps; a.packs = static_cast<const __bf16*>(packs); a.b1 = b1;
+  a.row_scale = row_scale; a.rows_per_scale = rows_per_scale; a.dgamma = dgamma; a.dbeta = dbeta; a.M = M;
+#define SV_MLP_BWD(CC, NW, PER_CU)                                                                        \
+  do {                                                                                                    \
+    a.ntiles = cdiv(M, NW * 32);                                                                          \
+    int grid = 256 * PER_CU; if (grid > a.ntiles) grid = a.ntiles;                                        \
+    hipLaunchKernelGGL((swin_mlp_bwd_kernel<CC, NW>), dim3(grid), dim3(NW * 64), 0, STREAM, a);           \
+  } while (0)
+  if (C == 96) SV_MLP_BWD(96, 4, 2);
+  else if (C == 128) SV_MLP_BWD(128, 4, 1);
+  else SV_MLP_BWD(192, 4, 1);
+#undef SV_MLP_BWD
+  return check_launch("sv_swin_mlp_bwd");
+}
+
+extern "C" int sv_swin_mlp_wgrad(const void* x1, const void* dx2, const float* ln_g, const float* ln_b, const void* w1_rows,
+                                 const void* w2t_rows, const float* b1, const float* row_scale, int rows_per_scale, float* dw1, float* db1,
+                                 float* dw2, float* db2, long long M, int C, float eps, void* stream) {
+  SV_REQUIRE(x1 && dx2 && ln_g && ln_b && w1_rows && w2t_rows && b1 && dw1 && db1 && dw2 && db2 && M > 0 && M < (1ll << 31) && mlp_supported(C),
+             "swin_mlp_wgrad: bad arguments (M=%lld C=%d)", M, C);
+  SV_REQUIRE((((uintptr_t)x1 | (uintptr_t)dx2 | (uintptr_t)w1_rows | (uintptr_t)w2t_rows) & 15) == 0 && rows_per_scale > 0, "swin_mlp_wgrad: alignment");
+  MlpWArgs a{};
+  a.x1 = static_cast<const __bf16*>(x1); a.dx2 = static_cast<const __bf16*>(dx2); a.ln_g = ln_g; a.ln_b = ln_b; a.eps = eps;
+  a.w1r = static_cast<const __bf16*>(w1_rows); a.w2tr = static_cast<const __bf16*>(w2t_rows); a.b1 = b1;
+  a.row_scale = row_scale; a.rows_per_scale = rows_per_scale; a.dw1 = dw1; a.db1 = db1; a.dw2 = dw2; a.db2 = db2; a.M = M;
+#define SV_MLP_WG(CC, NW, HCW)                                                                                  \
+  do {                                                                                                          \
+    a.HG = (4 * CC) / (NW * HCW);                                                                               \
+    long long splits = 256 / a.HG; if (splits < 1) splits = 1;                                                  \
+    long long tps = (M + splits - 1) / splits; tps = (tps + 127) / 128 * 128;                                   \
+    splits = (M + tps - 1) / tps;                                                                               \
+    a.tok_per_split = (int)tps;                                                                                 \
+    hipLaunchKernelGGL((swin_mlp_wgrad_kernel<CC, NW, HCW>), dim3((unsigned)(splits * a.HG)), dim3(NW * 64), 0, STREAM, a); \
+  } while (0)
+  if (C == 96) SV_MLP_WG(96, 6, 32);
+  else if (C == 128) SV_MLP_WG(128, 8, 16);
+  else SV_MLP_WG(192, 8, 16);
+#undef SV_MLP_WG
+  return check_launch("sv_swin_mlp_wgrad");
+}

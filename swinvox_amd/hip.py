@@ -83,6 +83,11 @@ _PROTOS = {
     "sv_window_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "sv_window_attention_bwd_workspace_floats": (C.c_size_t, None, [_I]),
     "sv_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
+    "sv_swin_mlp_supported": (_I, None, [_I]),
+    "sv_swin_mlp_pack": (_I, [_P, _P, _P, _I]),
+    "sv_swin_mlp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _F]),
+    "sv_swin_mlp_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _F]),
+    "sv_swin_mlp_wgrad": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _F]),
     "sv_cross_view_attention_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I]),
     "sv_cross_view_attention_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
     "sv_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _L]),
