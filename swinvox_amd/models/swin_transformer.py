@@ -155,6 +155,15 @@ def block_forward(blk: SwinBlock, x, I, training, stochastic, seeds):
     x1 = empty(M, Cd, like=x)
     ops.linear_fwd(att, M, blk.s_proj, blk.attn.proj.weight, x1, bias=blk.attn.proj.bias, residual=x, ldr=Cd, row_scale=sc1,
                    rows_per_scale=H * W)
+    if ops.fused_mlp_enabled(Cd):
+        # norm2 -> fc1 -> GELU -> fc2 -> drop-path -> +x1 in ONE kernel; the 4C-wide hidden activation never reaches HBM
+        packs = torch.empty(16 * Cd * Cd, dtype=torch.bfloat16, device=x.device)
+        call("sv_swin_mlp_pack", ptr(blk.mlp.fc1.weight), ptr(blk.mlp.fc2.weight), ptr(packs), Cd)
+        x2 = empty(M, Cd, like=x)
+        unit = 2.0 * M * Cd * 4 * Cd
+        ops.traced_call("sv_swin_mlp_fwd", 2 * unit, 4.0 * M * Cd, ptr(x1), ptr(x2), ptr(blk.norm2.weight), ptr(blk.norm2.bias), ptr(packs),
+                        ptr(blk.mlp.fc1.bias), ptr(blk.mlp.fc2.bias), ptr(sc2), H * W, M, Cd, float(blk.norm2.eps), tag=f"M={M} C={Cd}")
+        return x2, (x, m1, r1, ln1, qkv, att, sc1, sc2, x1, None, None, None, packs, None, I)
     ln2, m2, r2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, M, Cd)
     hpre = empty(M, 4 * Cd, like=x)
     h = empty(M, 4 * Cd, like=x)
@@ -171,6 +180,9 @@ def block_backward(blk: SwinBlock, ctx, dx2, grads):
     H = W = blk.res
     Cd, M = blk.dim, I * H * W
     # ---- MLP branch: x2 = x1 + s2 * fc2(gelu(fc1(ln2)))
+    if ln2 is None:
+        dx1 = _fused_mlp_backward(blk, x1, hpre, sc2, dx2, grads, M, Cd, H * W)
+        return _attention_backward(blk, x, m1, r1, ln1, qkv, att, sc1, dx1, grads, I, H, W, Cd, M)
     dbr = dx2
     if sc2 is not None:
         dbr = empty(M, Cd, like=x)
@@ -184,6 +196,37 @@ def block_backward(blk: SwinBlock, ctx, dx2, grads):
     ops.linear_dgrad(dh, M, blk.s_fc1, blk.s_fc1.pack_dgrad(blk.mlp.fc1.weight), dln2)
     ops.layernorm_bwd(dln2, x1, blk.norm2.weight, m2, r2, dx2, grads[blk.norm2.weight], grads[blk.norm2.bias], M, Cd, accumulate_dx=True)
     dx1 = dx2
+    return _attention_backward(blk, x, m1, r1, ln1, qkv, att, sc1, dx1, grads, I, H, W, Cd, M)
+
+
+def _fused_mlp_backward(blk, x1, packs, sc2, dx2, grads, M, Cd, HW):
+    """Data gradient (dx1 = dx2 + branch gradient, LayerNorm parameter gradients) and weight gradients of the fused MLP branch:
+    both recompute norm2 and the pre-activation from x1; the weight gradients run on the weight-gradient stream."""
+    unit = 2.0 * M * Cd * 4 * Cd
+    eps = float(blk.norm2.eps)
+    dx1 = empty(M, Cd, like=x1)
+    ops.traced_call("sv_swin_mlp_bwd", 3 * unit, 6.0 * M * Cd, ptr(x1), ptr(dx2), ptr(dx1), ptr(blk.norm2.weight), ptr(blk.norm2.bias), ptr(packs),
+                    ptr(blk.mlp.fc1.bias), ptr(sc2), HW, ptr(grads[blk.norm2.weight]), ptr(grads[blk.norm2.bias]), M, Cd, eps, tag=f"M={M} C={Cd}")
+    w1r, w2tr = blk.s_fc1.pack_fwd(blk.mlp.fc1.weight), blk.s_fc2.pack_dgrad(blk.mlp.fc2.weight)     # bf16 [4C][C] rows both
+
+    def launch():
+        ops.traced_call("sv_swin_mlp_wgrad", 4 * unit, 4.0 * M * Cd, ptr(x1), ptr(dx2), ptr(blk.norm2.weight), ptr(blk.norm2.bias), ptr(w1r), ptr(w2tr),
+                        ptr(blk.mlp.fc1.bias), ptr(sc2), HW, ptr(grads[blk.mlp.fc1.weight]), ptr(grads[blk.mlp.fc1.bias]),
+                        ptr(grads[blk.mlp.fc2.weight]), ptr(grads[blk.mlp.fc2.bias]), M, Cd, eps, tag=f"M={M} C={Cd}")
+
+    aw = ops._CTX.awg
+    if aw is not None:
+        aw.stream.wait_stream(torch.cuda.current_stream())
+        aw.held.append((x1, dx2, w1r, w2tr))
+        with torch.cuda.stream(aw.stream):
+            launch()
+    else:
+        launch()
+    return dx1
+
+
+def _attention_backward(blk, x, m1, r1, ln1, qkv, att, sc1, dx1, grads, I, H, W, Cd, M):
+    """x1 = x + s1 * proj(attn(qkv(ln1))): dx1 is consumed (accumulator of the residual path); returns dx."""
     # ---- attention branch: x1 = x + s1 * proj(attn(qkv(ln1)))
     dbr = dx1
     if sc1 is not None:

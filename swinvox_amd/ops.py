@@ -448,6 +448,27 @@ def set_pack_cache(cache) -> None:
     _CTX.packs = cache
 
 
+def traced_call(name, flops, nbytes, *args, tag=""):
+    """call() that books ALGORITHMIC flops / bytes with bench.py's tracer when it listens to `name`."""
+    tr = hip.TRACE
+    if tr is None or name not in tr.names:
+        return call(name, *args)
+    tr.begin(name, flops, nbytes, tag=tag)
+    call(name, *args)
+    tr.end()
+
+
+def fused_mlp_enabled(C: int) -> bool:
+    """The fused Swin MLP kernels (csrc/swin_mlp.hip) serve bf16 MFMA + bf16 storage and the channel counts they are built for."""
+    return (_STATE.get("fused_mlp", True) and _STATE["math"] == hip.MATH_BF16 and _STATE["store"] == torch.bfloat16
+            and hip.load().sv_swin_mlp_supported(C) == 1)
+
+
+def set_fused_mlp(on: bool) -> None:
+    """A/B switch: False routes every Swin MLP through the unfused LayerNorm / fc1 / fc2 chain of the contraction engine."""
+    _STATE["fused_mlp"] = bool(on)
+
+
 def colsum(x, rows, cols, ld, out, accumulate=True):
     call("sv_colsum", ptr(x), rows, cols, ld, ptr(out), 1 if accumulate else 0)
 
