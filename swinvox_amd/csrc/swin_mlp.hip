@@ -60,16 +60,32 @@ __global__ __launch_bounds__(256) void swin_mlp_pack_kernel(const float* __restr
   }
 }
 
-// GELU and its derivative from one erf / one exp (fast forms of common.h: the operands carry bf16 precision)
-__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
+// GELU (exact erf form of nn.GELU) and its derivative from one v_rcp_f32 and one v_exp_f32: erf by Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7 on exact arithmetic; the 1-ulp hardware reciprocal / exponential keep it below 1e-6, three orders under the bf16
+// rounding of the value that is stored).  __frcp_rn / a plain division would expand to the 11-instruction IEEE sequence: with 16
+// activations per lane and 32x32 accumulator tile the VALU, not the matrix pipe, would pace the kernel.
+__device__ __forceinline__ float phi_cdf(float x, float& ex) {   // Phi(x); ex = exp(-x^2 / 2)
   const float ax = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float ex = __expf(-ax * ax);                       // = exp(-x^2 / 2)
-  const float erfv = copysignf(1.f - poly * ex, x);
-  const float cdf = 0.5f * (1.f + erfv);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  ex = __builtin_amdgcn_exp2f(ax * ax * -1.44269504088896340736f);
+  const float half_erfc = 0.5f * poly * ex;               // 0.5 * erfc(|x| / sqrt 2)
+  return x >= 0.f ? 1.f - half_erfc : half_erfc;
+}
+__device__ __forceinline__ float gelu_fwd(float x) {
+#ifdef SV_GELU_SIGMOID_PROBE   // measurement probe only (never built into the library): x * sigmoid(1.5958 x + 0.0714 x^3), 7 VALU instructions
+  const float u = x * fmaf(x * x, -0.10294324f, -2.30220820f);
+  return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u));
+#else
+  float ex;
+  return x * phi_cdf(x, ex);
+#endif
+}
+__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
+  float ex;
+  const float cdf = phi_cdf(x, ex);
   g = x * cdf;
-  dg = cdf + x * 0.39894228040143267794f * ex;
+  dg = fmaf(x * 0.39894228040143267794f, ex, cdf);
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {   // registers 8s .. 8s+7 -> one bf16 fragment
@@ -111,12 +127,17 @@ __device__ __forceinline__ void stage_dma(const __bf16* const (&img)[NIMG], int 
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------------------
-template <int C, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void swin_mlp_fwd_kernel(const MlpArgs p) {
+// Workgroups of 4 waves (128 tokens), two per CU: the two run out of phase, so one's prologue (HBM latency of its rows, LayerNorm)
+// and store tail hide under the other's MFMA / GELU loop; with one 8-wave workgroup per CU every wave sat in the same phase.
+template <int C, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void swin_mlp_fwd_kernel(const MlpArgs p) {
   constexpr int NF = C / 16, NB = C / 32, HID = 4 * C, NPAIR = HID / 64, NT = NW * 64;
   constexpr int STAGE = 2 * 64 * C;                      // bf16 elements: W1F pair | W2F pair
-  __shared__ __attribute__((aligned(16))) __bf16 wbuf[2 * STAGE];
-  __shared__ float sb1[HID];
+  // ONE shared object: with a second one beside the LDS-DMA ring hipcc puts s_waitcnt vmcnt(0) in front of the first ds_read of every
+  // stage (it must assume the read aliases the DMA in flight) and the copy no longer runs under the MFMAs (cdna_hip_programming.md 5)
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE * 2 + HID * 4];
+  __bf16* wbuf = reinterpret_cast<__bf16*>(smem);
+  float* sb1 = reinterpret_cast<float*>(smem + 2 * STAGE * 2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const long long HC = (long long)HID * C;
@@ -165,48 +186,73 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void swin_mlp_fwd_kernel(const Mlp
     for (int i = 0; i < 16; ++i) acc2[b][i] = 0.f;
 
   stage_dma<C, NW, 2>(imgs, 0, wbuf, wave, lane);
+#pragma unroll 1
   for (int pr = 0; pr < NPAIR; ++pr) {
     const __bf16* st = wbuf + (pr & 1) * STAGE;
-    __syncthreads();                                     // stage pr has landed; everybody is done with the other buffer
-    if (pr + 1 < NPAIR) stage_dma<C, NW, 2>(imgs, pr + 1, wbuf + ((pr + 1) & 1) * STAGE, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of stage pr have landed ...
+    __syncthreads();                                     // ... and everybody's; everybody is done with the other buffer
+    if (pr + 1 < NPAIR) stage_dma<C, NW, 2>(imgs, pr + 1, wbuf + ((pr + 1) & 1) * STAGE, wave, lane);   // lands under the MFMAs below
+    // the two 32-unit sub-chunks of the stage run interleaved: two independent accumulator chains keep the matrix pipe issuing
+    f32x16 acc1[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc1[sub][i] = 0.f;
+    // every A fragment of the first product is requested before the first MFMA (ds_read latency ~ 4 MFMAs: fetched two at a time in
+    // front of their MFMA the matrix pipe idles); the fragments of the second product are requested in front of the GELU block
+    bf16x8 wa[2][NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) wa[sub][f] = *reinterpret_cast<const bf16x8*>(st + sub * 32 * C + f * 512 + lane * 8);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+        acc1[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[sub][f], xn[f], acc1[sub], 0, 0, 0);   // H^T chunk: rows = hidden, columns = tokens
+    bf16x8 wb[2][2][NB];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) wb[sub][s2][b] = *reinterpret_cast<const bf16x8*>(st + 64 * C + sub * 32 * C + (b * 2 + s2) * 512 + lane * 8);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 hb[2][2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-      f32x16 acc1;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
-      const __bf16* w1f = st + sub * 32 * C;
-#pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(w1f + f * 512 + lane * 8);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xn[f], acc1, 0, 0, 0);      // H^T chunk: rows = hidden, columns = tokens
-      }
       const int hid0 = (2 * pr + sub) * 32;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float v = acc1[i] + sb1[hid0 + (i & 3) + 8 * (i >> 2) + 4 * h];
-        acc1[i] = 0.5f * v * (1.f + erf_fast(v * 0.70710678118654752440f));
+        const float v = acc1[sub][i] + sb1[hid0 + (i & 3) + 8 * (i >> 2) + 4 * h];
+        acc1[sub][i] = gelu_fwd(v);
       }
-      const bf16x8 hb0 = pack8(acc1, 0), hb1 = pack8(acc1, 1);
-      const __bf16* w2f = st + 64 * C + sub * 32 * C;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(w2f + (b * 2 + 0) * 512 + lane * 8);
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(w2f + (b * 2 + 1) * 512 + lane * 8);
-        acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, hb0, acc2[b], 0, 0, 0);  // Y^T: rows = output channels, columns = tokens
-        acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hb1, acc2[b], 0, 0, 0);
-      }
+      hb[sub][0] = pack8(acc1[sub], 0); hb[sub][1] = pack8(acc1[sub], 1);
     }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[sub][s2][b], hb[sub][s2], acc2[b], 0, 0, 0);   // Y^T: rows = output channels, columns = tokens
   }
   // ---- epilogue: + bias, drop-path scale, + residual; lane (r, h) owns channels 32 b + 8 g + 4 h .. + 3 of token r
   if (valid) {
     const float sc = p.row_scale ? p.row_scale[tok / p.rows_per_scale] : 1.f;
+    bf16x4 resv[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) resv[b][g] = *reinterpret_cast<const bf16x4*>(p.x1 + tok * C + 32 * b + 8 * g + 4 * h);   // all in flight at once
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c0 = 32 * b + 8 * g + 4 * h;
         const float4 bi = *reinterpret_cast<const float4*>(p.b2 + c0);
-        const bf16x4 res = *reinterpret_cast<const bf16x4*>(p.x1 + tok * C + c0);
+        const bf16x4 res = resv[b][g];
         bf16x4 o;
         o[0] = (__bf16)((float)res[0] + sc * (acc2[b][4 * g + 0] + bi.x));
         o[1] = (__bf16)((float)res[1] + sc * (acc2[b][4 * g + 1] + bi.y));
@@ -219,19 +265,26 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void swin_mlp_fwd_kernel(const Mlp
 
 // ---- data gradient ------------------------------------------------------------------------------------------------------
 // dx1 = dx2 + LayerNormBackward( (s * dx2 . W2) * GELU'(hpre) . W1 ),  dgamma / dbeta of the LayerNorm accumulated per workgroup
-template <int C, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void swin_mlp_bwd_kernel(const MlpArgs p) {
+template <int C, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void swin_mlp_bwd_kernel(const MlpArgs p) {
   constexpr int NF = C / 16, NB = C / 32, HID = 4 * C, NPAIR = HID / 64, NT = NW * 64;
   constexpr int STAGE = 3 * 64 * C;                      // W1F pair | W2TF pair | W1TF pair
-  __shared__ __attribute__((aligned(16))) __bf16 wbuf[2 * STAGE];
-  __shared__ float sb1[HID];
-  __shared__ float sdg[C], sdb[C];
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE * 2 + (HID + 4 * C) * 4];   // one object (see the forward kernel)
+  __bf16* wbuf = reinterpret_cast<__bf16*>(smem);
+  float* sb1 = reinterpret_cast<float*>(smem + 2 * STAGE * 2);
+  float* sdg = sb1 + HID;
+  float* sdb = sdg + C;
+  // LayerNorm parameters from LDS: read from global memory they are invariant over the persistent tile loop, hipcc hoists all 3 C / 2
+  // per-lane values out of it and spills them around the main loop
+  float* sgam = sdb + C;
+  float* sbet = sgam + C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const long long HC = (long long)HID * C;
   const __bf16* const imgs[3] = {p.packs, p.packs + 2 * HC, p.packs + 3 * HC};
   for (int i = tid; i < HID; i += NT) sb1[i] = p.b1[i];
-  for (int i = tid; i < C; i += NT) { sdg[i] = 0.f; sdb[i] = 0.f; }
+  for (int i = tid; i < C; i += NT) { sdg[i] = 0.f; sdb[i] = 0.f; sgam[i] = p.ln_g[i]; sbet[i] = p.ln_b[i]; }
+  __syncthreads();
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const long long tok = (long long)tile * (NW * 32) + wave * 32 + r;
@@ -264,8 +317,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void swin_mlp_bwd_kernel(const Mlp
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const int c0 = 16 * f + 8 * h;
-        const float4 g0 = *reinterpret_cast<const float4*>(p.ln_g + c0), g1 = *reinterpret_cast<const float4*>(p.ln_g + c0 + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(p.ln_b + c0), b1v = *reinterpret_cast<const float4*>(p.ln_b + c0 + 4);
+        const float4 g0 = *reinterpret_cast<const float4*>(sgam + c0), g1 = *reinterpret_cast<const float4*>(sgam + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(sbet + c0), b1v = *reinterpret_cast<const float4*>(sbet + c0 + 4);
         const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
         const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
 #pragma unroll
@@ -280,13 +333,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void swin_mlp_bwd_kernel(const Mlp
 
     __syncthreads();                                     // previous tile: every wave has left its last stage
     stage_dma<C, NW, 3>(imgs, 0, wbuf, wave, lane);
+#pragma unroll 1
     for (int pr = 0; pr < NPAIR; ++pr) {
       const __bf16* st = wbuf + (pr & 1) * STAGE;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (pr + 1 < NPAIR) stage_dma<C, NW, 3>(imgs, pr + 1, wbuf + ((pr + 1) & 1) * STAGE, wave, lane);
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
-        f32x16 acc1, accd;
+        f32x16 acc1, accd;                               // two independent chains (pre-activation, dy . W2) interleave on the matrix pipe
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc1[i] = 0.f; accd[i] = 0.f; }
         const __bf16* w1f = st + sub * 32 * C;
@@ -306,17 +361,29 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void swin_mlp_bwd_kernel(const Mlp
           accd[i] *= dg;
         }
         const bf16x8 d0 = pack8(accd, 0), d1 = pack8(accd, 1);
+        __builtin_amdgcn_sched_barrier(0);               // do not hoist the next fragments above the GELU block (register pressure)
         const __bf16* w1tf = st + 128 * C + sub * 32 * C;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(w1tf + (b * 2 + 0) * 512 + lane * 8);
-          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(w1tf + (b * 2 + 1) * 512 + lane * 8);
           acc3[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, d0, acc3[b], 0, 0, 0);  // dLN^T: rows = channels, columns = tokens
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(w1tf + (b * 2 + 1) * 512 + lane * 8);
           acc3[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, d1, acc3[b], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- LayerNorm backward on the accumulator (lane (r, h): channels 32 b + 8 g + 4 h + k of token r)
+    // lane offset laundered per tile: otherwise hipcc materialises all 3 C / 2 per-lane LDS addresses of the epilogue once, outside the
+    // tile loop, and spills them around the main loop; with an opaque base they stay immediate offsets of the ds instructions
+    int lane_off = 4 * h;
+    asm volatile("" : "+v"(lane_off));
+    float* const lg_ = sgam + lane_off;
+    float* const ldg_ = sdg + lane_off;
+    float* const ldb_ = sdb + lane_off;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -325,7 +392,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void swin_mlp_bwd_kernel(const Mlp
         const int c0 = 32 * b + 8 * g + 4 * h;
         bf16x4 xr = V4<__bf16>::zero();
         if (valid) xr = *reinterpret_cast<const bf16x4*>(p.x1 + tok * C + c0);
-        const float4 gm = *reinterpret_cast<const float4*>(p.ln_g + c0);
+        const float4 gm = *reinterpret_cast<const float4*>(lg_ + 32 * b + 8 * g);
         const float gv[4] = {gm.x, gm.y, gm.z, gm.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -335,8 +402,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void swin_mlp_bwd_kernel(const Mlp
           s1 += gg; s2 += gg * xh;
           // dgamma / dbeta: totals over the 32 tokens of this lane half arrive in lanes 31 and 63
           const float tb = half_wave_total(d), tg = half_wave_total(d * xh);
-          if (r == 31) { atomicAdd(&sdb[c0 + k], tb); atomicAdd(&sdg[c0 + k], tg); }
+          if (r == 31) { atomicAdd(ldb_ + 32 * b + 8 * g + k, tb); atomicAdd(ldg_ + 32 * b + 8 * g + k, tg); }
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the 8 reduction chains of one channel group together (interleaving all 96 spills)
       }
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
@@ -349,7 +417,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void swin_mlp_bwd_kernel(const Mlp
           const int c0 = 32 * b + 8 * g + 4 * h;
           const bf16x4 xr = *reinterpret_cast<const bf16x4*>(p.x1 + tok * C + c0);
           const bf16x4 dr = *reinterpret_cast<const bf16x4*>(p.dx2 + tok * C + c0);
-          const float4 gm = *reinterpret_cast<const float4*>(p.ln_g + c0);
+          const float4 gm = *reinterpret_cast<const float4*>(lg_ + 32 * b + 8 * g);
           const float gv[4] = {gm.x, gm.y, gm.z, gm.w};
           bf16x4 o;
 #pragma unroll
@@ -376,18 +444,44 @@ struct MlpWArgs {
   long long M; int tok_per_split; int HG;
 };
 
-template <int C, int NW, int HCW>
+// Tiles: TT token rows of x1 and dx2 per step, DOUBLE-BUFFERED in LDS and filled by LDS-DMA while the previous tile is being
+// contracted.  A row record is the C/8 16-byte units of the row plus one pad unit (row stride = 8 banks mod 64: the fragment reads
+// below are conflict-free); one DMA instruction moves 64 / (C/8 + 1) whole records (the pad unit re-reads the row's last unit), so
+// the records stay contiguous as LDS-DMA requires.  LayerNorm (4 lanes per row) and the drop-path scale of dy then run in place.
+template <int C, int NW, int HCW, int TT>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void swin_mlp_wgrad_kernel(const MlpWArgs p) {
-  constexpr int NF = C / 32, NCB = C / 16, NHB = HCW / 16, HID = 4 * C, NT = NW * 64, TT = 128, LD = C + 8;
-  __shared__ __attribute__((aligned(16))) __bf16 xs[TT * LD];    // LayerNorm(x1) tile  [token][channel]
-  __shared__ __attribute__((aligned(16))) __bf16 ds[TT * LD];    // s * dx2 tile
+  constexpr int NF = C / 32, NCB = C / 16, NHB = HCW / 16, HID = 4 * C, NT = NW * 64;
+  constexpr int UPR = C / 8, RU = UPR + 1, LD = RU * 8, RPI = 64 / RU, NGRP = (TT + RPI - 1) / RPI, TILE = TT * LD;
+  // ONE shared object (see the forward kernel), and no ordinary global load inside the token loop: hipcc would drain the DMA of the next
+  // tile in front of its first use - LayerNorm parameters sit in LDS, the drop-path factors of a tile are fetched before its DMA wait
+  __shared__ __attribute__((aligned(16))) char smem_raw[4 * TILE * 2 + 2 * C * 4];
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);            // [buffer][x | dy][TT][LD]
+  float* sgam = reinterpret_cast<float*>(smem_raw + 4 * TILE * 2);
+  float* sbet = sgam + C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4, q = lr >> 2, pp = lr & 3;
+  for (int i = tid; i < C; i += NT) { sgam[i] = p.ln_g[i]; sbet[i] = p.ln_b[i]; }
   const int hg = blockIdx.x % p.HG, split = blockIdx.x / p.HG;
   const int h0 = (hg * NW + wave) * HCW;                         // first hidden unit of this wave
   const long long t_begin = (long long)split * p.tok_per_split;
   long long t_end = t_begin + p.tok_per_split;
   if (t_end > p.M) t_end = p.M;
+
+  auto tile_dma = [&](long long t0, int buf) {
+    const int rr = lane / RU, uu = lane % RU;
+#pragma unroll 1
+    for (int g = wave; g < NGRP; g += NW) {
+      const int row = g * RPI + rr;
+      if (rr < RPI && row < TT) {
+        long long tok = t0 + row;
+        if (tok >= t_end) tok = t_end - 1;                       // rows past the end are zeroed by the LayerNorm pass
+        const size_t off = (size_t)tok * C + (uu < UPR ? uu : UPR - 1) * 8;
+        __bf16* dst = smem + (size_t)(2 * buf) * TILE + (size_t)g * RPI * LD;
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.x1 + off), (lptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.dx2 + off), (lptr_t)(dst + TILE), 16, 0, 0);
+      }
+    }
+  };
 
   // per-wave constant B fragments: W1 rows / W2^T rows of the wave's hidden units (k = channels, 8 consecutive per lane)
   bf16x8 w1b[NHB][NF], w2b[NHB][NF];
@@ -412,60 +506,76 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void swin_mlp_wgrad_kernel(c
   for (int hb = 0; hb < NHB; ++hb) db1acc[hb] = 0.f;
   float db2acc = 0.f;
 
-  constexpr int UPR = C / 8;                 // 16-byte units per token row
-  for (long long t0 = t_begin; t0 < t_end; t0 += TT) {
-    __syncthreads();                         // the previous tile has been consumed
-    // ---- tile load: raw x1 and s * dx2 rows (contiguous in HBM), 16 bytes per unit
-    for (int u = tid; u < TT * UPR; u += NT) {
-      const int row = u / UPR, cu = u % UPR;
-      const long long tok = t0 + row;
-      bf16x8 xv = VecN<__bf16, 8>::zero(), dv = VecN<__bf16, 8>::zero();
-      if (tok < t_end) {
-        xv = *reinterpret_cast<const bf16x8*>(p.x1 + tok * C + cu * 8);
-        dv = *reinterpret_cast<const bf16x8*>(p.dx2 + tok * C + cu * 8);
-        if (p.row_scale) {
-          const float sc = p.row_scale[tok / p.rows_per_scale];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the fragment loads above are ordinary loads: retire them before any DMA
+  tile_dma(t_begin, 0);
+  int buf = 0;
+#pragma unroll 1
+  for (long long t0 = t_begin; t0 < t_end; t0 += TT, buf ^= 1) {
+    __bf16* xs = smem + (size_t)(2 * buf) * TILE;
+    __bf16* ds = xs + TILE;
+    // drop-path factors of this tile: it spans at most two images (rows_per_scale >= TT is checked on the host)
+    float sc_lo = 1.f, sc_hi = 1.f;
+    long long t_img = t_end;                                     // first token of the second image inside the tile
+    if (p.row_scale) {
+      const long long i_lo = t0 / p.rows_per_scale;
+      long long t_last = t0 + TT - 1; if (t_last >= t_end) t_last = t_end - 1;
+      sc_lo = p.row_scale[i_lo]; sc_hi = p.row_scale[t_last / p.rows_per_scale];
+      t_img = (i_lo + 1) * (long long)p.rows_per_scale;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's records of tile t0 have landed ...
+    __syncthreads();                                             // ... and everybody's; the other buffer has been consumed
+    // ---- in place: LayerNorm of x1 rows (4 lanes per row), drop-path scale of dy rows, zero rows past the end
+    for (int row = tid >> 2; row < TT; row += NT / 4) {
+      const int part = tid & 3;
+      const bool live = t0 + row < t_end;
+      __bf16* xr = xs + row * LD + part * (C / 4);
+      __bf16* dr = ds + row * LD + part * (C / 4);
+      bf16x8 v[C / 32];
+      float s1 = 0.f;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) dv[j] = (__bf16)(sc * (float)dv[j]);
+      for (int u = 0; u < C / 32; ++u) {
+        v[u] = *reinterpret_cast<const bf16x8*>(xr + 8 * u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1 += (float)v[u][j];
+      }
+      s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+      const float mean = s1 * (1.f / C);
+      float s2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < C / 32; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (float)v[u][j] - mean; s2 += d * d; }
+      s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+      const float rstd = rsqrtf(s2 * (1.f / C) + p.eps);
+      const float sc = t0 + row < t_img ? sc_lo : sc_hi;
+#pragma unroll
+      for (int u = 0; u < C / 32; ++u) {
+        const int c0 = part * (C / 4) + 8 * u;
+        const float4 g0 = *reinterpret_cast<const float4*>(sgam + c0), g1 = *reinterpret_cast<const float4*>(sgam + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(sbet + c0), b1q = *reinterpret_cast<const float4*>(sbet + c0 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1q.x, b1q.y, b1q.z, b1q.w};
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = live ? (__bf16)(((float)v[u][j] - mean) * rstd * gg[j] + bb[j]) : (__bf16)0.f;
+        *reinterpret_cast<bf16x8*>(xr + 8 * u) = o;
+        if (!live || p.row_scale) {
+          bf16x8 d = *reinterpret_cast<const bf16x8*>(dr + 8 * u);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) d[j] = live ? (__bf16)(sc * (float)d[j]) : (__bf16)0.f;
+          *reinterpret_cast<bf16x8*>(dr + 8 * u) = d;
         }
       }
-      *reinterpret_cast<bf16x8*>(xs + row * LD + cu * 8) = xv;
-      *reinterpret_cast<bf16x8*>(ds + row * LD + cu * 8) = dv;
     }
     __syncthreads();
-    // ---- LayerNorm in place (one thread per token row); rows past the end stay zero
-    if (tid < TT) {
-      __bf16* rowp = xs + tid * LD;
-      const bool live = t0 + tid < t_end;
-      float s = 0.f;
-      for (int c = 0; c < C; c += 8) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(rowp + c);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += (float)v[j];
-      }
-      const float mean = s * (1.f / C);
-      float qv = 0.f;
-      for (int c = 0; c < C; c += 8) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(rowp + c);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - mean; qv += d * d; }
-      }
-      const float rstd = rsqrtf(qv * (1.f / C) + p.eps);
-      for (int c = 0; c < C; c += 8) {
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(rowp + c);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = live ? (__bf16)(((float)v[j] - mean) * rstd * p.ln_g[c + j] + p.ln_b[c + j]) : (__bf16)0.f;
-        *reinterpret_cast<bf16x8*>(rowp + c) = v;
-      }
-    } else if (hg == 0 && tid >= TT && tid < TT + C) {     // bias gradient of fc2: column sums of the dy tile
-      const int c = tid - TT;
+    if (t0 + TT < t_end) tile_dma(t0 + TT, buf ^ 1);             // the next tile lands under the contraction below
+    if (hg == 0 && tid < C) {                                    // bias gradient of fc2: column sums of the (scaled) dy tile
       float s = 0.f;
 #pragma unroll 8
-      for (int row = 0; row < TT; ++row) s += (float)ds[row * LD + c];
+      for (int row = 0; row < TT; ++row) s += (float)ds[row * LD + tid];
       db2acc += s;
     }
-    __syncthreads();
-    // ---- the wave's hidden chunk against the four 32-token sub-tiles
+    // ---- the wave's hidden chunk against the 32-token sub-tiles
 #pragma unroll 1
     for (int sub = 0; sub < TT / 32; ++sub) {
       f32x4 Hh[2][NHB], Dh[2][NHB];
@@ -543,7 +653,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void swin_mlp_wgrad_kernel(c
     v += __shfl_xor(v, 32, 64);
     if (lg == 0) atomicAdd(p.db1 + h0 + 16 * hb + lr, v);
   }
-  if (hg == 0 && tid >= TT && tid < TT + C) atomicAdd(p.db2 + (tid - TT), db2acc);
+  if (hg == 0 && tid < C) atomicAdd(p.db2 + tid, db2acc);
 }
 
 static inline bool mlp_supported(int C) { return C == 96 || C == 128 || C == 192; }
@@ -576,10 +686,10 @@ extern "C" int sv_swin_mlp_fwd(const void* x1, void* x2, const float* ln_g, cons
   MlpArgs a{};
   a.x1 = static_cast<const __bf16*>(x1); a.out = static_cast<__bf16*>(x2); a.ln_g = ln_g; a.ln_b = ln_b; a.eps = eps;
   a.packs = static_cast<const __bf16*>(packs); a.b1 = b1; a.b2 = b2; a.row_scale = row_scale; a.rows_per_scale = rows_per_scale; a.M = M;
-#define SV_MLP_FWD(CC, NW) hipLaunchKernelGGL((swin_mlp_fwd_kernel<CC, NW>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), 0, STREAM, a)
-  if (C == 96) SV_MLP_FWD(96, 8);
-  else if (C == 128) SV_MLP_FWD(128, 8);
-  else SV_MLP_FWD(192, 4);
+#define SV_MLP_FWD(CC, NW, WPS) hipLaunchKernelGGL((swin_mlp_fwd_kernel<CC, NW, WPS>), dim3(cdiv(M, NW * 32)), dim3(NW * 64), 0, STREAM, a)
+  if (C == 96) SV_MLP_FWD(96, 4, 2);
+  else if (C == 128) SV_MLP_FWD(128, 4, 2);
+  else SV_MLP_FWD(192, 4, 1);
 #undef SV_MLP_FWD
   return check_launch("sv_swin_mlp_fwd");
 }
@@ -593,11 +703,11 @@ extern "C" int sv_swin_mlp_bwd(const void* x1, const void* dx2, void* dx1, const
   a.x1 = static_cast<const __bf16*>(x1); a.dx2 = static_cast<const __bf16*>(dx2); a.out = static_cast<__bf16*>(dx1);
   a.ln_g = ln_g; a.ln_b = ln_b; a.eps = eps; a.packs = static_cast<const __bf16*>(packs); a.b1 = b1;
   a.row_scale = row_scale; a.rows_per_scale = rows_per_scale; a.dgamma = dgamma; a.dbeta = dbeta; a.M = M;
-#define SV_MLP_BWD(CC, NW, PER_CU)                                                                        \
+#define SV_MLP_BWD(CC, NW, WPS)                                                                           \
   do {                                                                                                    \
     a.ntiles = cdiv(M, NW * 32);                                                                          \
-    int grid = 256 * PER_CU; if (grid > a.ntiles) grid = a.ntiles;                                        \
-    hipLaunchKernelGGL((swin_mlp_bwd_kernel<CC, NW>), dim3(grid), dim3(NW * 64), 0, STREAM, a);           \
+    int grid = 256 * WPS; if (grid > a.ntiles) grid = a.ntiles;                                           \
+    hipLaunchKernelGGL((swin_mlp_bwd_kernel<CC, NW, WPS>), dim3(grid), dim3(NW * 64), 0, STREAM, a);      \
   } while (0)
   if (C == 96) SV_MLP_BWD(96, 4, 2);
   else if (C == 128) SV_MLP_BWD(128, 4, 1);
@@ -612,22 +722,23 @@ extern "C" int sv_swin_mlp_wgrad(const void* x1, const void* dx2, const float* l
   SV_REQUIRE(x1 && dx2 && ln_g && ln_b && w1_rows && w2t_rows && b1 && dw1 && db1 && dw2 && db2 && M > 0 && M < (1ll << 31) && mlp_supported(C),
              "swin_mlp_wgrad: bad arguments (M=%lld C=%d)", M, C);
   SV_REQUIRE((((uintptr_t)x1 | (uintptr_t)dx2 | (uintptr_t)w1_rows | (uintptr_t)w2t_rows) & 15) == 0 && rows_per_scale > 0, "swin_mlp_wgrad: alignment");
+  SV_REQUIRE(!row_scale || rows_per_scale >= 128, "swin_mlp_wgrad: rows_per_scale (%d) must be >= 128 (a token tile spans at most two scale groups)", rows_per_scale);
   MlpWArgs a{};
   a.x1 = static_cast<const __bf16*>(x1); a.dx2 = static_cast<const __bf16*>(dx2); a.ln_g = ln_g; a.ln_b = ln_b; a.eps = eps;
   a.w1r = static_cast<const __bf16*>(w1_rows); a.w2tr = static_cast<const __bf16*>(w2t_rows); a.b1 = b1;
   a.row_scale = row_scale; a.rows_per_scale = rows_per_scale; a.dw1 = dw1; a.db1 = db1; a.dw2 = dw2; a.db2 = db2; a.M = M;
-#define SV_MLP_WG(CC, NW, HCW)                                                                                  \
+#define SV_MLP_WG(CC, NW, HCW, TT)                                                                              \
   do {                                                                                                          \
     a.HG = (4 * CC) / (NW * HCW);                                                                               \
     long long splits = 256 / a.HG; if (splits < 1) splits = 1;                                                  \
-    long long tps = (M + splits - 1) / splits; tps = (tps + 127) / 128 * 128;                                   \
+    long long tps = (M + splits - 1) / splits; tps = (tps + TT - 1) / TT * TT;                                  \
     splits = (M + tps - 1) / tps;                                                                               \
     a.tok_per_split = (int)tps;                                                                                 \
-    hipLaunchKernelGGL((swin_mlp_wgrad_kernel<CC, NW, HCW>), dim3((unsigned)(splits * a.HG)), dim3(NW * 64), 0, STREAM, a); \
+    hipLaunchKernelGGL((swin_mlp_wgrad_kernel<CC, NW, HCW, TT>), dim3((unsigned)(splits * a.HG)), dim3(NW * 64), 0, STREAM, a); \
   } while (0)
-  if (C == 96) SV_MLP_WG(96, 6, 32);
-  else if (C == 128) SV_MLP_WG(128, 8, 16);
-  else SV_MLP_WG(192, 8, 16);
+  if (C == 96) SV_MLP_WG(96, 6, 32, 128);
+  else if (C == 128) SV_MLP_WG(128, 8, 16, 128);
+  else SV_MLP_WG(192, 8, 16, 64);
 #undef SV_MLP_WG
   return check_launch("sv_swin_mlp_wgrad");
 }

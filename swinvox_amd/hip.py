@@ -13,7 +13,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libswinvox_hip.so")
+LIB_PATH = os.environ.get("SV_HIP_LIB") or os.path.join(_HERE, "libswinvox_hip.so")   # SV_HIP_LIB: A/B builds of the kernels
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_LRELU = 0, 1, 2, 3
 MATH_F32, MATH_BF16 = 0, 1
