@@ -7,9 +7,10 @@ N > 1 - the bucketed RCCL gradient all-reduce.  Workload per GPU (weak scaling):
 224x224 (BASELINE config "Full pipeline ... n_views=8, 1xMI355X"), train mode (dropout / drop-path / batch-stat
 BatchNorm active), inputs resident in HBM before the timed region.
 
-By default the step is captured once into a hipGraph (swinvox_amd/graph.py) and the timed region replays it: the ~1 400
-launches of a step cost ~50 ms of host time when enqueued one by one, about as much as the GPU needs to run them.  The
-replayed graph contains the same kernels on the same three streams; `--no-graph` times the eager path.
+The timed region enqueues every launch from the host (~1 300 launches on three HIP streams; the host needs ~21 ms per step with
+an idle queue, the GPU ~70 ms, so the host runs ahead).  `--graph` replays the step from ONE hipGraph captured on a single stream
+(swinvox_amd/graph.py: host cost 0.4 ms per step; measured round 2: 77.6 ms per step against 72.7 eager, because the single-stream
+graph gives up the overlap of the encoder branches, and a three-stream capture replays slower than eager on ROCm 7.2: 96.8 ms).
 
   python bench.py --gpus 1 --steps 10 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -110,7 +111,8 @@ def main():
     ap.add_argument("--variant", default="tiny", choices=["tiny", "base"], help="Swin-T (the metric) or Swin-B (BASELINE config 5)")
     ap.add_argument("--math", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--storage", default="bf16", choices=["bf16", "f32"], help="HBM element type of the activations inside the modules")
-    ap.add_argument("--no-graph", action="store_true", help="enqueue every launch of every step from the host instead of replaying a hipGraph")
+    ap.add_argument("--fp8-attention", action="store_true", help="QK^T / PV of the window attention forward on fp8 (e4m3) MFMA operands (BASELINE config 5)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from one hipGraph (captured on a single stream) instead of enqueueing every launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run every module on one stream (no branch / weight-gradient streams)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra untimed pass that times the engine without stream overlap")
@@ -147,7 +149,8 @@ def main():
     S.set_math(args.math)
     S.set_storage(args.storage if args.math == "bf16" else "f32")
     S.set_overlap(not args.no_overlap)
-    use_graph = not args.no_graph
+    S.set_attention_fp8(args.fp8_attention)
+    use_graph = args.graph
     torch.manual_seed(1234)              # the SAME weights on every rank (the reducer also broadcasts rank 0's at construction)
     cfg = S.default_cfg()
     nets = [Encoder(cfg, variant=args.variant), Decoder(cfg), Merger(cfg), Refiner(cfg)]
@@ -192,7 +195,7 @@ def main():
     for _ in range(args.warmup):
         eager_step()
     if use_graph:
-        graphed = GraphedStep(compute, warmup=1, device=dev)
+        graphed = GraphedStep(compute, warmup=1, device=dev)      # captured with set_overlap(False): one stream
 
         def step():
             total = graphed()
@@ -290,8 +293,9 @@ def main():
                                    f"attention, decoder, merger, refiner), fwd+2xBCE+bwd, train mode, B={B} samples x V={V} views of 224x224 per GPU",
                        "global_batch": world * B, "n_views": V, "images_per_gpu": B * V,
                        "parallelism": f"dp{world} (sample-sharded, RCCL gradient all-reduce)" if world > 1 else "single GPU",
-                       "launch": "hipGraph replay of the captured step" if use_graph else "eager (one host launch per kernel)",
+                       "launch": "hipGraph replay of the step captured on one stream" if use_graph else "eager (one host launch per kernel, three streams)",
                        "math": (f"bf16 MFMA inputs, fp32 accumulate, {S.get_storage()} activations / fp32 weights, statistics and gradients of weights in HBM"
+                                + ("; window-attention forward QK^T / PV on fp8 e4m3 MFMA operands (per-tile scales)" if args.fp8_attention else "")
                                 if args.math == "bf16" else "exact fp32 MFMA, fp32 storage")},
             "roofline": {"bound": "hbm" if hbm_bound else "mfma",
                          "kernel": "implicit-GEMM contraction engine (igemm_kernel / gemm_dense_kernel / wgrad_kernel: Linear/Conv/ConvTranspose fwd+dgrad+wgrad)",

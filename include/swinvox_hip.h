@@ -34,7 +34,9 @@ extern "C" {
 
 enum { SV_ACT_NONE = 0, SV_ACT_RELU = 1, SV_ACT_GELU = 2, SV_ACT_LRELU = 3 };
 #define SV_BN_SLOTS 16 /* BatchNorm statistic accumulators are [SV_BN_SLOTS][2*C] doubles (contention spreading) */
-enum { SV_MATH_F32 = 0, SV_MATH_BF16 = 1 }; /* MFMA input type of the contraction kernels; accumulation stays fp32 */
+enum { SV_MATH_F32 = 0, SV_MATH_BF16 = 1, SV_MATH_FP8 = 2 }; /* MFMA input type of the contraction kernels; accumulation stays fp32.
+   SV_MATH_FP8 (OCP e4m3, per-tile scales) is accepted by sv_window_attention_fwd only (QK^T and PV of BASELINE configuration 5);
+   sv_window_attention_bwd treats it as SV_MATH_BF16 */
 /* Storage type of ACTIVATIONS (and activation gradients) in HBM.  Entry points with an `act_dtype` argument take their
  * activation tensors as void*: every such tensor of one call has this element type.  Parameters, parameter gradients,
  * statistics (mean/rstd/scale/shift/sums), workspaces and drop-path scales are always fp32 (or double where noted).

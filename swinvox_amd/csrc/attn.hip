@@ -735,6 +735,117 @@ __global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<
   }
 }
 
+// ---- fp8 (OCP e4m3) variant of the forward core: BASELINE configuration 5 ("fp8 MFMA QK/AV") -------------------------------------
+// q (already times head_dim^-0.5), k, v and the softmax probabilities go to the matrix pipe as e4m3 (v_mfma_f32_16x16x32_fp8_fp8,
+// fp32 accumulate).  Scales are per (window, head) TILE - finer than per tensor and free of an extra pass over HBM: the workgroup takes
+// the absolute maximum of its q / k / v tile while the rows travel through registers and maps it to 224 (half of e4m3's 448, head room
+// for the rounding); probabilities (<= 1) are scaled by 256, so that everything above 2^-17 survives as a subnormal.  Scores and
+// outputs are rescaled in fp32; bias, mask and softmax stay fp32.  The backward keeps bf16 operands and recomputes P from bf16 q / k.
+constexpr int LDQ_8 = 40;    // byte row stride of the fp8 q / k tiles (32 + 8: 8-byte fragment reads, rows 10 banks apart)
+constexpr int LDP_8 = 72;    // byte row stride of the fp8 P and V^T tiles
+__device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (uint32_t)w;
+}
+__device__ __forceinline__ uint8_t one_fp8(float a) { return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(a, 0.f, 0, false) & 0xff); }
+
+template <typename AT>
+__global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_fp8_kernel(const WinArgsT<AT> p) {
+  __shared__ __attribute__((aligned(16))) uint8_t Qs[64 * LDQ_8], Ks[64 * LDQ_8], Vt[HD * LDP_8], Ps[64 * LDP_8];
+  __shared__ float bt[176];
+  __shared__ float amax[4][3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  int chunk, head;
+  if (!wg_chunk_head((p.ntasks + p.tasks_per_wave - 1) / p.tasks_per_wave, p.heads, chunk, head)) return;   // uniform over the workgroup
+  const int nWx = p.W / 7, nW = (p.H / 7) * nWx;
+  const int ld = 3 * p.C, colq = head * HD;
+  for (int i = tid; i < 169; i += 256) bt[i] = p.table[i * p.heads + head];
+  for (int i = tid; i < HD * LDP_8; i += 256) Vt[i] = 0;               // key columns >= 49 stay zero
+  __syncthreads();
+  float bias[4][4];
+  strip_bias(bias, bt, lane, wave);
+  const long long task0 = (long long)chunk * p.tasks_per_wave;
+  for (int tt = 0; tt < p.tasks_per_wave; ++tt) {
+    const long long task = task0 + tt;
+    if (task >= p.ntasks) break;                                         // uniform over the workgroup
+    const TokMap tm = task_map(task, nW, nWx, p.H, p.W, p.shift);
+    float4 q4[2], k4[2], v4[2];
+    float mq = 0.f, mk = 0.f, mv = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int r = (tid >> 3) + 32 * it, ch = (tid & 7) * 4;
+      q4[it] = make_float4(0.f, 0.f, 0.f, 0.f); k4[it] = q4[it]; v4[it] = q4[it];
+      if (r < WT) {
+        const AT* src = p.qkv + (size_t)tm.row(r) * ld + colq + ch;
+        q4[it] = ld4f(src); k4[it] = ld4f(src + p.C); v4[it] = ld4f(src + 2 * p.C);
+      }
+      q4[it].x *= p.scale; q4[it].y *= p.scale; q4[it].z *= p.scale; q4[it].w *= p.scale;
+      mq = fmaxf(mq, fmaxf(fmaxf(fabsf(q4[it].x), fabsf(q4[it].y)), fmaxf(fabsf(q4[it].z), fabsf(q4[it].w))));
+      mk = fmaxf(mk, fmaxf(fmaxf(fabsf(k4[it].x), fabsf(k4[it].y)), fmaxf(fabsf(k4[it].z), fabsf(k4[it].w))));
+      mv = fmaxf(mv, fmaxf(fmaxf(fabsf(v4[it].x), fabsf(v4[it].y)), fmaxf(fabsf(v4[it].z), fabsf(v4[it].w))));
+    }
+    mq = wave_max(mq); mk = wave_max(mk); mv = wave_max(mv);
+    __syncthreads();                                                     // previous window's tiles (and maxima) are consumed
+    if (lane == 0) { amax[wave][0] = mq; amax[wave][1] = mk; amax[wave][2] = mv; }
+    __syncthreads();
+    mq = fmaxf(fmaxf(amax[0][0], amax[1][0]), fmaxf(amax[2][0], amax[3][0]));
+    mk = fmaxf(fmaxf(amax[0][1], amax[1][1]), fmaxf(amax[2][1], amax[3][1]));
+    mv = fmaxf(fmaxf(amax[0][2], amax[1][2]), fmaxf(amax[2][2], amax[3][2]));
+    const float sq = mq > 0.f ? 224.f / mq : 1.f, sk = mk > 0.f ? 224.f / mk : 1.f, sv = mv > 0.f ? 224.f / mv : 1.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int r = (tid >> 3) + 32 * it, ch = (tid & 7) * 4;
+      *reinterpret_cast<uint32_t*>(Qs + r * LDQ_8 + ch) = pack4_fp8(q4[it].x * sq, q4[it].y * sq, q4[it].z * sq, q4[it].w * sq);
+      *reinterpret_cast<uint32_t*>(Ks + r * LDQ_8 + ch) = pack4_fp8(k4[it].x * sk, k4[it].y * sk, k4[it].z * sk, k4[it].w * sk);
+      if (r < WT) {
+        const uint32_t w = pack4_fp8(v4[it].x * sv, v4[it].y * sv, v4[it].z * sv, v4[it].w * sv);
+        Vt[(ch + 0) * LDP_8 + r] = (uint8_t)(w & 0xff); Vt[(ch + 1) * LDP_8 + r] = (uint8_t)((w >> 8) & 0xff);
+        Vt[(ch + 2) * LDP_8 + r] = (uint8_t)((w >> 16) & 0xff); Vt[(ch + 3) * LDP_8 + r] = (uint8_t)(w >> 24);
+      }
+    }
+    __syncthreads();
+    f32x4 s[4];
+    {
+      const long a = *reinterpret_cast<const long*>(Qs + (wave * 16 + lr) * LDQ_8 + lg * 8);
+      const float un = 1.f / (sq * sk);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const long b = *reinterpret_cast<const long*>(Ks + (nt * 16 + lr) * LDQ_8 + lg * 8);
+        s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[nt][j] *= un;
+      }
+    }
+    bias_mask_softmax_strip(s, bias, tm, lane, p.shift > 0 && (tm.wy == p.H / 7 - 1 || tm.wx == nWx - 1), wave);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Ps[(wave * 16 + lg * 4 + j) * LDP_8 + nt * 16 + lr] = one_fp8(s[nt][j] * 256.f);
+    __syncthreads();
+    f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const long a = *reinterpret_cast<const long*>(Ps + (wave * 16 + lr) * LDP_8 + ks * 32 + lg * 8);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const long b = *reinterpret_cast<const long*>(Vt + (nt * 16 + lr) * LDP_8 + ks * 32 + lg * 8);
+        o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b, a, o[nt], 0, 0, 0);   // transposed block: O[q = lr][d = lg*4 + j]
+      }
+    }
+    {
+      const int q = wave * 16 + lr;
+      const float un = 1.f / (256.f * sv);
+      if (q < WT) {
+        AT* dst = p.out + (size_t)tm.row(q) * p.C + colq + lg * 4;
+        st4f(dst, make_float4(o[0][0] * un, o[0][1] * un, o[0][2] * un, o[0][3] * un));
+        st4f(dst + 16, make_float4(o[1][0] * un, o[1][1] * un, o[1][2] * un, o[1][3] * un));
+      }
+    }
+  }
+}
+
 constexpr int ATTN_DT_SLOTS = 16;   // slot images of the relative-position-bias gradient (see sv_window_attention_bwd)
 
 template <typename AT>
@@ -904,7 +1015,7 @@ static int win_check(const void* qkv, const float* table, int I, int H, int W, i
   SV_REQUIRE(shift >= 0 && shift < 7 && (shift == 0 || (H > 7 && W > 7)), "window_attention: bad shift %d for map %dx%d", shift, H, W);
   SV_REQUIRE(((uintptr_t)qkv & 15) == 0, "window_attention: qkv must be 16-byte aligned");
   SV_REQUIRE_ACT(act_dtype);
-  SV_REQUIRE(act_dtype == SV_F32 || math == SV_MATH_BF16, "window_attention: bf16 activations require SV_MATH_BF16");
+  SV_REQUIRE(act_dtype == SV_F32 || math == SV_MATH_BF16 || math == SV_MATH_FP8, "window_attention: bf16 activations require SV_MATH_BF16 / SV_MATH_FP8");
   return SV_OK;
 }
 
@@ -926,6 +1037,20 @@ extern "C" int sv_window_attention_fwd(const void* qkv, const float* table, void
   SV_REQUIRE(out, "window_attention_fwd: null out");
   const int ntasks = I * (H / 7) * (W / 7);
   hipStream_t s = (hipStream_t)stream;
+  if (math == SV_MATH_FP8) {    // e4m3 operands for QK^T and PV (forward only; the backward entry point treats SV_MATH_FP8 as bf16)
+    int tpb = (int)((long long)ntasks * heads / 2048); if (tpb < 1) tpb = 1; if (tpb > 8) tpb = 8;
+    dim3 grid(wg_grid(cdiv(ntasks, tpb), heads));
+    if (act_dtype == SV_BF16) {
+      WinArgsT<__bf16> a = win_args<__bf16>(qkv, table, out, nullptr, nullptr, nullptr, I, H, W, C, heads, shift);
+      a.tasks_per_wave = tpb;
+      hipLaunchKernelGGL(win_attn_fwd_wg_fp8_kernel<__bf16>, grid, dim3(256), 0, s, a);
+    } else {
+      WinArgs a = win_args<float>(qkv, table, out, nullptr, nullptr, nullptr, I, H, W, C, heads, shift);
+      a.tasks_per_wave = tpb;
+      hipLaunchKernelGGL(win_attn_fwd_wg_fp8_kernel<float>, grid, dim3(256), 0, s, a);
+    }
+    return check_launch("sv_window_attention_fwd");
+  }
   if (math == SV_MATH_BF16) {   // workgroup per window; a workgroup walks tpb windows of one head (>= ~2048 short workgroups:
     // the forward task is brief, oversubscribing the CUs balances better than one exact wave - measured)
     int tpb = (int)((long long)ntasks * heads / 2048); if (tpb < 1) tpb = 1; if (tpb > 8) tpb = 8;
@@ -954,7 +1079,7 @@ extern "C" int sv_window_attention_bwd(const void* qkv, const float* table, cons
   SV_REQUIRE(dout && dqkv && dtable && ((uintptr_t)dout & 15) == 0, "window_attention_bwd: null/unaligned argument");
   const int ntasks = I * (H / 7) * (W / 7);
   hipStream_t s = (hipStream_t)stream;
-  if (math == SV_MATH_BF16) {   // workgroup per window, tpb windows of one head per workgroup
+  if (math == SV_MATH_BF16 || math == SV_MATH_FP8) {   // workgroup per window, tpb windows of one head per workgroup
     const int tpb = wg_tasks_per_block(ntasks, heads, 3);
     dim3 grid(wg_grid(cdiv(ntasks, tpb), heads));
     if (act_dtype == SV_BF16) {

@@ -1,9 +1,10 @@
 """hipGraph replay of a whole step of the hot path.
 
-One forward + loss + backward of the four modules is ~1 400 kernel launches on three HIP streams (encoder branches, weight
-gradients); enqueueing them through ctypes costs ~50 ms of host time per step, about what the GPU needs to run them.
-`GraphedStep` captures the launch sequence of one step - every stream that forks from the capturing stream joins the
-capture through its events - into ONE hipGraph and replays it: the host cost of a step becomes one hipGraphLaunch.
+One forward + loss + backward of the four modules is ~1 300 kernel launches (on three HIP streams when the branches overlap);
+enqueueing them through ctypes costs ~21 ms of host time per step.  `GraphedStep` captures the launch sequence of one step into ONE
+hipGraph and replays it: the host cost of a step becomes one hipGraphLaunch (0.4 ms).  It pays when the host is the bottleneck
+(small per-GPU batches); at the benchmark batch the GPU needs ~70 ms per step and the eager three-stream path is faster (numbers
+in __init__).
 
 The captured step is the same code path as the eager one (the modules do not know about the capture).  What a capture
 freezes, and how it is handled:
@@ -29,7 +30,7 @@ from . import hip, ops
 
 class GraphedStep:
     def __init__(self, fn: Callable[[], object], static_inputs: Sequence[torch.Tensor] = (), warmup: int = 3,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, single_stream: bool = True):
         """fn(): one step on the static inputs (closure); its return value (tensor / tuple of tensors / None) is kept as the
         static output.  `warmup` eager calls run first on a side stream (first-use paths: weight-pack registration, arena
         sizing, lazy stream creation must not be captured)."""
@@ -41,7 +42,14 @@ class GraphedStep:
         self.device = dev
         self.epoch = torch.zeros(1, dtype=torch.int32, device=dev)
         prev = ops._STATE.get("seed_epoch")
+        prev_overlap = ops.overlap_enabled()
         ops.set_seed_epoch(self.epoch)
+        # single_stream (default): the capture runs with set_overlap(False).  Measured on ROCm 7.2 / MI355X at B = 32 x V = 8: eager on three
+        # streams 72.7 ms per step (host 21 ms with an idle queue), a graph captured across the three streams 96.8 ms (fork / join edges
+        # replay slower than eager launches), a single-stream graph 77.6 ms at 0.4 ms of host time - the form to use when the host is
+        # the bottleneck (small batches).
+        if single_stream:
+            ops.set_overlap(False)
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -57,6 +65,7 @@ class GraphedStep:
                 self.output = fn()
         finally:
             ops.set_seed_epoch(prev)
+            ops.set_overlap(prev_overlap)
         self.replays = 0
 
     def copy_inputs(self, *tensors: torch.Tensor) -> None:

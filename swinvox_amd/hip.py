@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SV_HIP_LIB") or os.path.join(_HERE, "libswinvox_hip.so")   # SV_HIP_LIB: A/B builds of the kernels
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_LRELU = 0, 1, 2, 3
-MATH_F32, MATH_BF16 = 0, 1
+MATH_F32, MATH_BF16, MATH_FP8 = 0, 1, 2   # MATH_FP8: window-attention forward only (QK^T / PV in OCP e4m3)
 F32, BF16 = 0, 1      # SV_F32 / SV_BF16: storage element of the activation tensors of a call
 
 

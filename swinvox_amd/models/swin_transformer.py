@@ -148,7 +148,7 @@ def block_forward(blk: SwinBlock, x, I, training, stochastic, seeds):
     ops.linear_fwd(ln1, M, blk.s_qkv, blk.attn.qkv.weight, qkv, bias=blk.attn.qkv.bias)
     att = empty(M, Cd, like=x)
     call("sv_window_attention_fwd", ptr(qkv), ptr(blk.attn.relative_position_bias_table), ptr(att), I, H, W, Cd, blk.heads, blk.shift,
-         ops._STATE["math"])
+         ops.attention_math())
     dp = blk.drop_path if (training and stochastic) else 0.0
     sc1 = _drop_scale(I, dp, seeds(), x) if dp > 0 else None
     sc2 = _drop_scale(I, dp, seeds(), x) if dp > 0 else None

@@ -464,6 +464,17 @@ def fused_mlp_enabled(C: int) -> bool:
             and hip.load().sv_swin_mlp_supported(C) == 1)
 
 
+def set_attention_fp8(on: bool) -> None:
+    """BASELINE configuration 5: QK^T and PV of the Swin window attention FORWARD on fp8 (OCP e4m3) MFMA operands with per-(window, head)
+    scales; everything else (and the whole backward) keeps bf16 operands.  Needs set_math('bf16')."""
+    _STATE["attn_fp8"] = bool(on)
+
+
+def attention_math() -> int:
+    """math code of the window-attention forward call"""
+    return hip.MATH_FP8 if (_STATE.get("attn_fp8") and _STATE["math"] == hip.MATH_BF16) else _STATE["math"]
+
+
 def set_fused_mlp(on: bool) -> None:
     """A/B switch: False routes every Swin MLP through the unfused LayerNorm / fc1 / fc2 chain of the contraction engine."""
     _STATE["fused_mlp"] = bool(on)

@@ -129,6 +129,25 @@ def test_oracle_matches_golden_vectors():
         assert 1.0 < float(refined.std()) < 3.0       # calibrated logits, not the degenerate init_weights regime
 
 
+def test_swin_b_pin_and_golden():
+    """BASELINE config 5's encoder variant: the manifest records the oracle-vs-transformers pin of the Swin-B backbone, the oracle
+    reproduces its committed golden features, and the product's holder tree has the same parameters."""
+    man = json.load(open(os.path.join(GOLD, "manifest.json")))
+    for i in range(4):
+        assert man["pins"][f"swin_b_vs_hf_stage{i}_maxdiff"] < 1e-4 * max(1.0, man["pins"][f"swin_b_vs_hf_stage{i}_absmax"])
+    case = man["cases"]["swin_b_B1_V2"]
+    enc = O.Encoder(O.default_cfg(), variant="base")
+    O.seeded_weights_(enc, seed=case["weights_seed"])
+    enc.eval()
+    with torch.no_grad():
+        f = enc(synth_images(1, 2, case["seed"]))
+    gold = np.load(os.path.join(GOLD, "case_swin_b_B1_V2.npz"))["features"]
+    assert np.abs(f.numpy() - gold).max() < 1e-4 * np.abs(gold).max()
+    p = Encoder(S.default_cfg(), variant="base")
+    assert list(p.state_dict().keys()) == list(enc.state_dict().keys())
+    assert sum(q.numel() for q in p.parameters()) == man["pins"]["swin_b_encoder_params"] == 104832376
+
+
 def test_iou_edge_cases():
     """core/test.py:141-153: both empty -> 1.0; prediction empty, gt not -> 0."""
     z = torch.full((1, 32, 32, 32), -20.0)

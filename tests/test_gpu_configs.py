@@ -13,7 +13,8 @@ from swinvox_amd.models import Decoder, Encoder, Merger, Refiner  # noqa: E402
 
 from swinvox_amd.losses import bce_with_logits as bce  # noqa: E402  (sv_bce_logits behind an autograd node)
 CASES = [dict(B=2, V=1), dict(B=1, V=24), dict(B=3, V=5), dict(B=2, V=2, multi=False), dict(B=2, V=3, cva=False), dict(B=2, V=2, stages=[1, 3]),
-         dict(B=1, V=2, stages=[0, 1, 2])]      # no stage 3: timm's FeatureListNet drops layers_3, so must the state_dict
+         dict(B=1, V=2, stages=[0, 1, 2]),      # no stage 3: timm's FeatureListNet drops layers_3, so must the state_dict
+         dict(B=1, V=2, variant="base")]        # Swin-B encoder (BASELINE config 5): embed 128, depths 2/2/18/2, heads 4/8/16/32
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()).replace(" ", ""))
@@ -28,7 +29,8 @@ def test_config_variant_matches_the_oracle(dev, case):
         if "stages" in case:
             c.NETWORK.SWIN_T_STAGES = case["stages"]
     torch.manual_seed(0)
-    onets = [O.Encoder(ocfg), O.Decoder(ocfg), O.Merger(ocfg), O.Refiner(ocfg)]
+    variant = case.get("variant", "tiny")
+    onets = [O.Encoder(ocfg, variant=variant), O.Decoder(ocfg), O.Merger(ocfg), O.Refiner(ocfg)]
     for i, n in enumerate(onets):
         O.seeded_weights_(n, seed=50 + i)
         n.train()
@@ -37,7 +39,7 @@ def test_config_variant_matches_the_oracle(dev, case):
                 m.p = 0.0
             if isinstance(m, O.model.SwinBlock):
                 m.dp = 0.0
-    pnets = [Encoder(pcfg), Decoder(pcfg), Merger(pcfg), Refiner(pcfg)]
+    pnets = [Encoder(pcfg, variant=variant), Decoder(pcfg), Merger(pcfg), Refiner(pcfg)]
     if "stages" in case:     # backbone stages after the last requested one do not exist (timm FeatureListNet / notebook 40,339,770 KAT)
         last = max(case["stages"])
         keys = [k for k in pnets[0].state_dict() if k.startswith("swin_transformer.model.layers_")]
@@ -75,3 +77,32 @@ def test_config_variant_matches_the_oracle(dev, case):
     assert n32 == sum(1 for n in pnets for _ in n.parameters())           # every parameter of the variant received a gradient
     assert abs(l32 - ref) < 1e-3 and e32 < 2e-3 * max(1.0, float(refined_o.abs().max())) and f32      # fp32: 1e-3 (north_star)
     assert f16 and abs(l16 - ref) < 3e-2 * max(1.0, abs(ref))
+
+
+def test_swin_b_encoder_matches_the_golden_vector(dev):
+    """Swin-B encoder variant against the committed fp32 golden features (tests/golden/make_swin_b_pin.py: oracle Encoder(variant="base"),
+    whose backbone is pinned against transformers' SwinModel(embed_dim=128, depths=[2,2,18,2], num_heads=[4,8,16,32]) to 1.4e-5)."""
+    import json
+    import os
+    import numpy as np
+    from swinvox_amd import goldens
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    case = json.load(open(os.path.join(gdir, "manifest.json")))["cases"]["swin_b_B1_V2"]
+    gold = torch.from_numpy(np.load(os.path.join(gdir, "case_swin_b_B1_V2.npz"))["features"])
+    enc = Encoder(S.default_cfg(), variant="base")
+    goldens.seeded_fill_(enc, case["weights_seed"])
+    assert sum(p.numel() for p in enc.parameters()) == 104832376
+    enc.to(dev).eval()
+    x = goldens.synth_images(1, 2, case["seed"]).to(dev)
+    S.set_math("f32")
+    with torch.no_grad():
+        f = enc(x).cpu()
+    assert float((f - gold).abs().max()) < 1e-3 * float(gold.abs().max())
+    S.set_math("bf16")
+    S.set_storage("bf16")
+    try:
+        with torch.no_grad():
+            f16 = enc(x).cpu()
+    finally:
+        S.set_math("f32")
+    assert bool(torch.isfinite(f16).all()) and float((f16 - gold).abs().mean()) < 0.1 * float(gold.abs().mean()) + 1e-2
