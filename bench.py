@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run every module on one stream (no branch / weight-gradient streams)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra untimed pass that times the engine without stream overlap")
     ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-golden IoU report")
+    ap.add_argument("--profile", action="store_true", help="for rocprofv3 runs: warm-up + timed steps only, no instrumentation passes, short JSON line")
     ap.add_argument("--detail", action="store_true", help="print the per-geometry timing table of the contraction engine to stderr")
     args = ap.parse_args()
 
@@ -217,6 +218,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dp_stats = reducer.stats() if reducer is not None else None
+    if args.profile:
+        if rank == 0:
+            print(json.dumps({"metric": "views/sec (profiling run: no roofline / cpu legs)", "value": world * args.batch * args.views * args.steps / dt,
+                              "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+                              "steps_executed": args.steps + args.warmup + (2 if use_graph else 0)}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # ---- untimed instrumentation passes (every rank runs them: their gradient all-reduces are collectives) -------------
     # (1) the same step enqueued eagerly with HIP events around every engine / attention launch, streams overlapping as in the

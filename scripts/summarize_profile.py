@@ -17,8 +17,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def family(name: str) -> str:
     n = name.split("(")[0]
-    if "igemm_kernel" in n or "wgrad_kernel" in n or "gemm_dense_kernel" in n:
+    if "swin_mlp" in n:
+        for k in ("swin_mlp_fwd_kernel", "swin_mlp_bwd_kernel", "swin_mlp_wgrad_kernel", "swin_mlp_pack_kernel"):
+            if k in n:
+                return "fused Swin MLP: " + k
+    if "igemm_kernel" in n or ("wgrad_kernel" in n and "stencil" not in n) or "gemm_dense_kernel" in n:
         return "contraction engine (igemm_kernel + gemm_dense_kernel + wgrad_kernel)"
+    if "win_attn_fwd" in n:
+        return "window attention forward (win_attn_fwd_*)"
+    if "win_attn_bwd" in n:
+        return "window attention backward (win_attn_bwd_*)"
+    if "bn_bwd" in n or "scale_shift_act" in n or "bn_finalize" in n or "bn_stats" in n:
+        return "BatchNorm passes (bn_bwd_* + scale_shift_act_* + bn_finalize + bn_stats)"
+    if "ln_fwd" in n or "ln_bwd" in n or "lnl_" in n:
+        return "LayerNorm passes (ln_* + lnl_*)"
+    if "stencil3" in n:
+        return "merger stencils (stencil3_*)"
     return n.replace("void ", "").strip()[-60:]
 
 
@@ -27,6 +41,7 @@ def main():
     ap.add_argument("--stats")
     ap.add_argument("--fetch")
     ap.add_argument("--write")
+    ap.add_argument("--mfma", help="PMC pass with SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE")
     ap.add_argument("--tag", default="r1")
     ap.add_argument("--steps-in-trace", type=int, default=4)
     ap.add_argument("--steps-in-pmc", type=int, default=2)
@@ -66,6 +81,29 @@ def main():
                      "WRITE_SIZE_GB_per_step": wr.get(k, [0, 0.0])[1] / 1024 ** 2 / a.steps_in_pmc,
                      "hbm_bytes_per_launch_corrected": (2 * fe[k][1] + wr.get(k, [0, 0.0])[1]) * 1024 / n}
         out["pmc_traffic"] = pm
+    if a.mfma:
+        # MFMA utilisation per kernel family: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the SIMDs: 32 per v_mfma_f32_32x32x16_bf16,
+        # 16 per 16x16x32 - MI355X_MICROARCH.md cycle constants) against the SIMD-cycles the dispatch had: GRBM_GUI_ACTIVE (summed over the
+        # 8 XCDs) / 8 x 1024 SIMDs.  Calibration: the fused MLP forward issues a known number of MFMAs (see profiles/README.md).
+        f = glob.glob(os.path.join(a.mfma, "*", "*_counter_collection.csv"))[0]
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        cnt = collections.defaultdict(int)
+        for r in csv.DictReader(open(f)):
+            k = family(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                cnt[k] += 1
+        mf = {}
+        for k, c in sorted(agg.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0.0))[:14]:
+            gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+            simd_cycles = gui / 8.0 * 1024.0
+            mf[k] = {"launches_per_step": cnt[k] / a.steps_in_pmc,
+                     "SQ_VALU_MFMA_BUSY_CYCLES_per_step": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / a.steps_in_pmc,
+                     "SQ_BUSY_CYCLES_per_step": c.get("SQ_BUSY_CYCLES", 0.0) / a.steps_in_pmc,
+                     "SQ_WAVE_CYCLES_per_step": c.get("SQ_WAVE_CYCLES", 0.0) / a.steps_in_pmc,
+                     "GRBM_GUI_ACTIVE_per_step": gui / a.steps_in_pmc,
+                     "mfma_busy_fraction_of_simd_cycles": (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles) if simd_cycles else None}
+        out["mfma_utilisation"] = mf
     p = os.path.join(ROOT, "profiles", f"{a.tag}_summary.json")
     json.dump(out, open(p, "w"), indent=1)
     print("wrote", p)
