@@ -43,7 +43,7 @@ def sync_module_states(modules: Sequence[torch.nn.Module], group=None, src: int 
 
 class GradAllReducer:
     def __init__(self, modules: Sequence[torch.nn.Module], bucket_bytes: int = 64 << 20, group=None, sync_states: bool = True,
-                 hooks: bool = True):
+                 hooks: bool = True, early_groups: bool = True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.modules = list(modules)
@@ -53,7 +53,7 @@ class GradAllReducer:
         self._bucket_of: Dict[torch.nn.Parameter, int] = {}
         self._early_groups: Dict[int, List[List[int]]] = {}     # id(module) -> bucket indices per announced group
         for m in self.modules:
-            groups = m.grad_groups() if hooks and hasattr(m, "grad_groups") else None
+            groups = m.grad_groups() if hooks and early_groups and hasattr(m, "grad_groups") else None
             plists = groups if groups else [[p for p in m.parameters()]]
             early = []
             for pl in plists:
