@@ -105,8 +105,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32,
-                    help="samples per GPU (x --views images each); 32 = the reference's cfg.CONST.BATCH_SIZE (config.py:64)")
+    ap.add_argument("--batch", type=int, default=64,
+                    help="samples per GPU (x --views images each).  64 x 8 views = 512 images per step use ~76 GB of the 288 GB; the "
+                         "reference's cfg.CONST.BATCH_SIZE (config.py:64) is 32 for its 16-GB-class Colab GPU (round 2: 3 560 views/s at 32, 3 774 at 64)")
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--variant", default="tiny", choices=["tiny", "base"], help="Swin-T (the metric) or Swin-B (BASELINE config 5)")
     ap.add_argument("--math", default="bf16", choices=["bf16", "f32"])

@@ -237,9 +237,9 @@ def test_patch_merge_layernorm(dev):
     assert rel(dx, x.grad.reshape(-1, C0)) < TOL and rel(dg, gm.grad) < TOL
 
 
-def test_ln_image(dev):
+@pytest.mark.parametrize("I,Cc,H", [(3, 96, 14), (37, 192, 7)])   # 37 images: the backward splits the images over several slices (atomics)
+def test_ln_image(dev, I, Cc, H):
     g = torch.Generator().manual_seed(4)
-    I, Cc, H = 3, 96, 14
     x = torch.randn(I, H, H, Cc, generator=g, requires_grad=True)                 # NHWC data
     w = (1 + 0.1 * torch.randn(Cc, H, H, generator=g)).requires_grad_(True)       # reference [C,H,W] affine
     b = (0.1 * torch.randn(Cc, H, H, generator=g)).requires_grad_(True)
