@@ -249,6 +249,17 @@ int sv_swin_mlp_wgrad(const void* x1, const void* dx2, const float* ln_g, const 
                       const float* b1, const float* row_scale, int rows_per_scale, float* dw1, float* db1, float* dw2, float* db2,
                       long long M, int C, float eps, void* stream);
 
+/* Layout kernels of the ResNet stem (models/encoder.py:22: Conv2d(3, 64, 7, stride 2, pad 3) as a 4x4 / stride-1 convolution on the
+ * space-to-depth image [I][112][112][(sy, sx, c) = 16]) and of the merger's stencil weights (merger.py:20-54):
+ *  sv_stem_space_to_depth: images [I,3,224,224] -> x16;  sv_stem_pack: w [64,3,7,7] fp32 -> [64][16 taps][16] (out_dtype);
+ *  sv_stem_unpack_grad: dw [64,3,7,7] += dw16 [64][16][4][4];
+ *  sv_merger_pack: w [cout][cin][27] fp32 -> bf16 forward pack [16][27][16 | 48] or data-gradient pack [16 | 48][27][16] (taps flipped);
+ *                  concat = 1: the 36 input channels sit at columns 12 g + j of the four 12-wide planes.                              */
+int sv_stem_space_to_depth(const void* images, void* x16, int I, int act_dtype, void* stream);
+int sv_stem_pack(const float* w, void* wp, int out_dtype, void* stream);
+int sv_stem_unpack_grad(const float* dw16, float* dw, void* stream);
+int sv_merger_pack(const float* w, void* wp_bf16, int cout, int cin, int dgrad, int concat, void* stream);
+
 /* harness-side kernels on fp32 module outputs */
 int sv_mean_views(const float* vol, float* out, int B, int V, int S, void* stream);                      /* core/train.py:246 */
 int sv_bce_logits(const float* x, const float* t, long long n, float* loss_accum, float* dx, const float* gscale_dev, void* stream); /* core/train.py:165,249,255 */

@@ -519,6 +519,87 @@ using namespace sv;
 #define CA(p) static_cast<const AT*>(p)
 #define MA(p) static_cast<AT*>(p)
 
+// ---- layout kernels of the ResNet stem in its 4x4 / stride-1 formulation on the space-to-depth image (models/encoder.py) and of the
+//      merger's 16-channel stencil weights: the re-indexing that used to be torch index ops on the path
+namespace sv {
+// x16[i][oy][ox][(sy, sx, c)] = img[i][c][2 oy + sy][2 ox + sx] (c < 3), 0 for the pad channel c = 3; one thread per (i, oy, ox, sy): 8 outputs
+template <typename AT>
+__global__ __launch_bounds__(256) void stem_s2d_kernel(const AT* __restrict__ img, AT* __restrict__ x16, long long n) {
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+    const int sy = (int)(t & 1); long long r = t >> 1;
+    const int ox = (int)(r % 112); r /= 112;
+    const int oy = (int)(r % 112); const long long i = r / 112;
+    const AT* src = img + (i * 3) * 224 * 224 + (size_t)(2 * oy + sy) * 224 + 2 * ox;
+    AT* dst = x16 + ((i * 112 + oy) * 112 + ox) * 16 + sy * 8;
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dst[sx * 4 + c] = src[(size_t)c * 224 * 224 + sx];
+      stf(dst + sx * 4 + 3, 0.f);
+    }
+  }
+}
+// wp[co][(ty, tx)][(sy, sx, c)] = w[co][c][2 ty + sy - 1][2 tx + sx - 1] inside the 7x7 kernel and c < 3, else 0
+template <typename WT>
+__global__ void stem_pack_kernel(const float* __restrict__ w, WT* __restrict__ wp) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 64 * 256) return;
+  const int co = idx >> 8, tap = (idx >> 4) & 15, s = idx & 15;
+  const int ty = tap >> 2, tx = tap & 3, sy = s >> 3, sx = (s >> 2) & 1, c = s & 3;
+  const int ky = 2 * ty + sy - 1, kx = 2 * tx + sx - 1;
+  const bool ok = c < 3 && ky >= 0 && ky < 7 && kx >= 0 && kx < 7;
+  wp[idx] = (WT)(ok ? w[((co * 3 + c) * 7 + ky) * 7 + kx] : 0.f);
+}
+// dw[co][c][ky][kx] += dw16[co][(sy, sx, c)][ty][tx]  (native weight-gradient layout of the 4x4 formulation)
+__global__ void stem_unpack_grad_kernel(const float* __restrict__ dw16, float* __restrict__ dw) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 64 * 3 * 49) return;
+  const int kx = idx % 7, ky = (idx / 7) % 7, c = (idx / 49) % 3, co = idx / 147;
+  const int ty = (ky + 1) >> 1, sy = (ky + 1) & 1, tx = (kx + 1) >> 1, sx = (kx + 1) & 1;
+  dw[idx] += dw16[((co * 16 + (sy * 8 + sx * 4 + c)) * 4 + ty) * 4 + tx];
+}
+// merger.py:20-54 weights [cout][cin][27] -> bf16 stencil packs: forward [16][27][ncols] with wp[co][tap][col(ci)] = w[co][ci][tap];
+// data-gradient [ncols][27][16] with wp[col(ci)][26 - tap][co] = w[co][ci][tap]; col(ci) = 12 (ci / 9) + ci % 9 for the 36-channel concat
+__global__ void merger_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int cout, int cin, int ncols, int dgrad, int cat) {
+  const int total = 16 * 27 * ncols;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int co, tap, col;
+    if (!dgrad) { col = idx % ncols; tap = (idx / ncols) % 27; co = idx / (27 * ncols); }
+    else { co = idx % 16; tap = 26 - (idx / 16) % 27; col = idx / (16 * 27); }
+    const int ci = cat ? ((col % 12) < 9 ? (col / 12) * 9 + col % 12 : -1) : col;
+    const bool ok = co < cout && ci >= 0 && ci < cin;
+    wp[idx] = (__bf16)(ok ? w[((size_t)co * cin + ci) * 27 + tap] : 0.f);
+  }
+}
+}  // namespace sv
+using namespace sv;
+
+extern "C" int sv_stem_space_to_depth(const void* images, void* x16, int I, int act_dtype, void* stream) {
+  SV_REQUIRE(images && x16 && I > 0, "stem_space_to_depth: bad arguments");
+  SV_REQUIRE_ACT(act_dtype);
+  const long long n = (long long)I * 112 * 112 * 2;
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(stem_s2d_kernel<AT>, dim3(grid_for(n)), dim3(256), 0, STREAM, CA(images), MA(x16), n););
+  return check_launch("sv_stem_space_to_depth");
+}
+extern "C" int sv_stem_pack(const float* w, void* wp, int out_dtype, void* stream) {
+  SV_REQUIRE(w && wp, "stem_pack: bad arguments");
+  SV_REQUIRE_ACT(out_dtype);
+  if (out_dtype == SV_BF16) hipLaunchKernelGGL(stem_pack_kernel<__bf16>, dim3(64), dim3(256), 0, STREAM, w, static_cast<__bf16*>(wp));
+  else hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(64), dim3(256), 0, STREAM, w, static_cast<float*>(wp));
+  return check_launch("sv_stem_pack");
+}
+extern "C" int sv_stem_unpack_grad(const float* dw16, float* dw, void* stream) {
+  SV_REQUIRE(dw16 && dw, "stem_unpack_grad: bad arguments");
+  hipLaunchKernelGGL(stem_unpack_grad_kernel, dim3(cdiv(64 * 147, 256)), dim3(256), 0, STREAM, dw16, dw);
+  return check_launch("sv_stem_unpack_grad");
+}
+extern "C" int sv_merger_pack(const float* w, void* wp_bf16, int cout, int cin, int dgrad, int concat, void* stream) {
+  SV_REQUIRE(w && wp_bf16 && cout > 0 && cout <= 16 && cin > 0 && (concat ? cin == 36 : cin <= 16), "merger_pack: bad arguments (cout=%d cin=%d)", cout, cin);
+  const int ncols = concat ? 48 : 16;
+  hipLaunchKernelGGL(merger_pack_kernel, dim3(cdiv(16 * 27 * ncols, 256)), dim3(256), 0, STREAM, w, static_cast<__bf16*>(wp_bf16), cout, cin, ncols, dgrad ? 1 : 0, concat ? 1 : 0);
+  return check_launch("sv_merger_pack");
+}
+
 extern "C" int sv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream) {
   SV_REQUIRE(src && dst && n > 0, "cast: bad arguments");
   SV_REQUIRE_ACT(src_dtype); SV_REQUIRE_ACT(dst_dtype);

@@ -123,16 +123,13 @@ class Encoder(HipModule):
     # ---- ResNet stem on the space-to-depth image --------------------------------------------------------
     def _stem_pack(self):
         """[64,3,7,7] -> forward pack [cout][tap (ty,tx)][16 = (sy,sx,c)] of the 4x4 formulation (ky = 2ty+sy-1, kx = 2tx+sx-1)."""
-        w = self.resnet[0].weight.detach()
-        w8 = w.new_zeros(64, 4, 8, 8)
-        w8[:, :3, 1:, 1:] = w
-        wp = w8.view(64, 4, 4, 2, 4, 2).permute(0, 2, 4, 3, 5, 1).reshape(64, 16, 16)      # [co,c,ty,sy,tx,sx] -> [co,ty,tx,sy,sx,c]
-        return wp.to(ops._STATE["store"]).contiguous()
+        wp = empty(64 * 16 * 16, like=self.resnet[0].weight)
+        call("sv_stem_pack", ptr(self.resnet[0].weight), ptr(wp), ops.hip.ACT)
+        return wp
 
     def _stem_fwd(self, images, I, tr):
-        x16 = zeros(I, 112, 112, 2, 2, 4, like=images)                   # channel 3 of every (sy, sx) group stays zero
-        x16[..., :3].copy_(images.view(I, 3, 112, 2, 112, 2).permute(0, 2, 4, 3, 5, 1))
-        x16 = x16.view(I * 112 * 112, 16)
+        x16 = empty(I * 112 * 112, 16, like=images)                       # [.., (sy, sx, c)], channel 3 of every (sy, sx) group = 0
+        call("sv_stem_space_to_depth", ptr(images), ptr(x16), I)
         sp, bn, M = self._stem_spec, self.resnet[1], I * 112 * 112
         y = empty(M, 64, like=x16)
         st = BatchNormState(bn, M, tr)
@@ -149,8 +146,7 @@ class Encoder(HipModule):
         st.backward(dz, 64, None, 64, y, 64, dy, 64, grads[bn.weight], grads[bn.bias], ACT_RELU, 0.0)
         dw16 = ops.fzeros(64, 16, 4, 4, like=dy)                         # native layout of the 4x4 formulation: [co][(sy,sx,c)][ty][tx]
         self._stem_spec.wgrad(dy, x16, I, (1, 112, 112), dw16, async_ok=False)   # read back right below
-        g8 = dw16.view(64, 2, 2, 4, 4, 4).permute(0, 3, 4, 1, 5, 2).reshape(64, 4, 8, 8)   # -> [co, c, 2ty+sy, 2tx+sx]
-        grads[conv.weight].add_(g8[:, :3, 1:, 1:])
+        call("sv_stem_unpack_grad", ptr(dw16), ptr(grads[conv.weight]))  # dw[co][c][ky][kx] += dw16[co][(sy,sx,c)][ty][tx]
 
     # ------------------------------------------------------------------------------------------------
     def _fwd(self, images, save):

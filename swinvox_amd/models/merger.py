@@ -59,17 +59,10 @@ class Merger(HipModule):
     def _stencil_pack(self, li, dgrad):
         """bf16 weights for csrc/stencil.hip: forward [16][27][16G] (memory input channels), data-gradient
         [16*NT][27][16] (rows = memory channels of the conv input, taps flipped).  Tiny tensors: a few torch index ops."""
-        w = self._layer(li)[0].weight.detach()
-        cout, cin = w.shape[0], w.shape[1]
-        cols = self._cat_cols if li == 4 else torch.arange(9, device=w.device)
-        wv = w.reshape(cout, cin, 27)
-        if not dgrad:
-            wp = fzeros(16, 27, 48 if li == 4 else 16, like=w)
-            wp[:cout, :, cols] = wv.permute(0, 2, 1)
-        else:
-            wp = fzeros(48 if li == 4 else 16, 27, 16, like=w)
-            wp[cols, :, :cout] = wv.flip(2).permute(1, 2, 0)
-        return wp.to(torch.bfloat16).contiguous()
+        w = self._layer(li)[0].weight
+        wp = torch.empty(16 * 27 * (48 if li == 4 else 16), dtype=torch.bfloat16, device=w.device)
+        call("sv_merger_pack", ptr(w), ptr(wp), w.shape[0], w.shape[1], 1 if dgrad else 0, 1 if li == 4 else 0)
+        return wp
 
     def _conv_fwd(self, li, x, ldi, y, ldc, stats, w5p=None):
         conv, I = self._layer(li)[0], y.shape[0] // VOX
