@@ -330,6 +330,13 @@ def main():
                             "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None,
                             "GB/s": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] > 0 else None}
                         for k, v in (isumm if isumm is not None else summ).items()},
+            # the other hand-written MFMA kernels of the Swin blocks against THEIR bound min(MFMA peak, algorithmic intensity x 8 TB/s)
+            "roofline_kernels": {k: (lambda v: {"TFLOP/s": v["flops"] / (v["ms"] * 1e-3) / 1e12, "GB/s": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
+                                                "intensity_flop_per_byte": v["flops"] / v["bytes"],
+                                                "bound_TFLOP/s": min(peak, v["flops"] / v["bytes"] * PEAK_HBM_GBS * 1e9 / 1e12),
+                                                "frac_of_bound": (v["flops"] / (v["ms"] * 1e-3) / 1e12) / min(peak, v["flops"] / v["bytes"] * PEAK_HBM_GBS * 1e9 / 1e12)})(v)
+                                 for k, v in (isumm if isumm is not None else summ).items()
+                                 if k not in ENGINE and v["ms"] > 0 and v["flops"] > 0 and v["bytes"] > 0},
             "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
             "model_flops_tflops_per_gpu": (3 * FWD_GFLOP_PER_VIEW.get(V, 19.4) * 1e9 * value / world / 1e12) if args.variant == "tiny" else None,
             "data_parallel": {"world_size": (dist.get_world_size() if world > 1 else 1), "backend": (backend if world > 1 else None),

@@ -147,8 +147,10 @@ def block_forward(blk: SwinBlock, x, I, training, stochastic, seeds):
     qkv = empty(M, 3 * Cd, like=x)
     ops.linear_fwd(ln1, M, blk.s_qkv, blk.attn.qkv.weight, qkv, bias=blk.attn.qkv.bias)
     att = empty(M, Cd, like=x)
-    call("sv_window_attention_fwd", ptr(qkv), ptr(blk.attn.relative_position_bias_table), ptr(att), I, H, W, Cd, blk.heads, blk.shift,
-         ops.attention_math())
+    # algorithmic work of the core (49-token windows, no padding): QK^T + PV = 4 * 49 * 32 flop per (token, head); bytes: qkv in, out
+    esz = 2.0 if x.dtype == torch.bfloat16 else 4.0
+    ops.traced_call("sv_window_attention_fwd", 4.0 * 49 * 32 * M * blk.heads, esz * 4 * M * Cd, ptr(qkv), ptr(blk.attn.relative_position_bias_table),
+                    ptr(att), I, H, W, Cd, blk.heads, blk.shift, ops.attention_math(), tag=f"M={M} C={Cd}")
     dp = blk.drop_path if (training and stochastic) else 0.0
     sc1 = _drop_scale(I, dp, seeds(), x) if dp > 0 else None
     sc2 = _drop_scale(I, dp, seeds(), x) if dp > 0 else None
@@ -237,8 +239,10 @@ def _attention_backward(blk, x, m1, r1, ln1, qkv, att, sc1, dx1, grads, I, H, W,
     ops.linear_dgrad(dbr, M, blk.s_proj, blk.s_proj.pack_dgrad(blk.attn.proj.weight), datt)
     dqkv = empty(M, 3 * Cd, like=x)
     ws = ops.zeros_f64(8 * 169 * blk.heads, x.device)    # sv_window_attention_bwd_workspace_floats(heads) floats, zero on entry
-    call("sv_window_attention_bwd", ptr(qkv), ptr(blk.attn.relative_position_bias_table), ptr(datt), ptr(dqkv),
-         ptr(grads[blk.attn.relative_position_bias_table]), ptr(ws), I, H, W, Cd, blk.heads, blk.shift, ops._STATE["math"])
+    esz = 2.0 if x.dtype == torch.bfloat16 else 4.0     # backward = 2.5 x the forward products (recomputed P, dP, dQ, dK, dV); bytes: qkv + dout in, dqkv out
+    ops.traced_call("sv_window_attention_bwd", 10.0 * 49 * 32 * M * blk.heads, esz * 7 * M * Cd, ptr(qkv), ptr(blk.attn.relative_position_bias_table),
+                    ptr(datt), ptr(dqkv), ptr(grads[blk.attn.relative_position_bias_table]), ptr(ws), I, H, W, Cd, blk.heads, blk.shift,
+                    ops._STATE["math"], tag=f"M={M} C={Cd}")
     ops.linear_wgrad(dqkv, ln1, M, blk.s_qkv, grads[blk.attn.qkv.weight], grads[blk.attn.qkv.bias])
     dln1 = empty(M, Cd, like=x)
     ops.linear_dgrad(dqkv, M, blk.s_qkv, blk.s_qkv.pack_dgrad(blk.attn.qkv.weight), dln1)
