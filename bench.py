@@ -237,7 +237,8 @@ def main():
     # (1) the same step enqueued eagerly with HIP events around every engine / attention launch, streams overlapping as in the
     #     timed region: per-kernel durations (events cannot be recorded inside a graph replay);
     # (2) once more on ONE stream: durations undisturbed by whatever runs beside the kernel -> the roofline figures.
-    names = set(ENGINE) | {"sv_window_attention_fwd", "sv_window_attention_bwd", "sv_swin_mlp_fwd", "sv_swin_mlp_bwd", "sv_swin_mlp_wgrad"}
+    names = set(ENGINE) | {"sv_window_attention_fwd", "sv_window_attention_bwd", "sv_swin_mlp_fwd", "sv_swin_mlp_bwd", "sv_swin_mlp_wgrad",
+                               "sv_tconv4s2_fwd"}
     traced_steps = 2
     tracer = hip.Tracer(names) if rank == 0 else None
     eager_step()

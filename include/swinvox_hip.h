@@ -121,6 +121,12 @@ size_t sv_stencil3_wgrad_workspace_floats(int cout, int cin);
 int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int groups, const void* dy, int lddy, int cout_load,
                       float* dw, float* dbias, float* workspace, int cout, int cin, int c_stride, int c_valid, int I, int D, int H, int W,
                       long long x_plane_stride, int act_dtype, void* stream);
+/* ConvTranspose3d(kernel 4, stride 2, padding 1), 32 input channels -> 8 output channels (rows of 8 bf16; cout < 8 leaves zero columns),
+ * bf16 operands, on an LDS halo brick: the decoder's last up-sampling layer (models/decoder.py:37-40).  x: [I][D][H][W][32];
+ * w_packed: the forward pack [cout][64 taps][32] of sv_pack_weight (swap = 1); out: [I][2D][2H][2W][8] = value + bias;
+ * stats as in sv_epilogue.stats.  D, H, W must be multiples of 4, 4, 8. */
+int sv_tconv4s2_fwd(const void* x, const void* w_packed, const float* bias, void* out, double* stats, int I, int D, int H, int W,
+                    int cin, int cout, void* stream);
 /* dst[a][t][b] (b padded with zeros to pad_to) from the fp32 parameter src[a][b][t] (swap=0), or dst[b][t][a..pad_to] (swap=1);
  * dst elements are out_dtype (SV_F32 / SV_BF16) */
 int sv_pack_weight(const float* src, void* dst, int A, int B, int T, int swap, int pad_to, int out_dtype, void* stream);

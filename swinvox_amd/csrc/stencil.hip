@@ -360,6 +360,124 @@ __global__ __launch_bounds__(256, G == 1 ? 3 : 1) void stencil3_wgrad_kernel(con
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// ConvTranspose3d(k = 4, stride 2, pad 1) with <= 8 output channels on an LDS halo brick (the decoder's last up-sampling layer,
+// models/decoder.py:37-40: 32 -> 8 channels, 16^3 -> 32^3).  The generic engine gathers 8 taps x 64 B from L2 for every 16-byte output row
+// (8.6 GB of gathers for 0.27 GB of output at I = 512: 1.6 ms) and pads 8 output channels to a 16-wide tile on top.
+// Here a workgroup owns a 4 x 4 x 8 brick of INPUT positions j (+ 1 halo): output voxel o = 2 j + a (a = parity per axis) receives the two taps
+// d = 0, 1 per axis from input i = j - 1 + a + d with kernel index k = a ? 2 - 2 d : 3 - 2 d, i.e. every parity class is a 2 x 2 x 2-tap
+// stencil on the same halo brick with its own 8 x 32 weight slices.  MFMA 16x16x32: rows = 16 positions of one class, k = one tap's 32
+// channels (one 16-byte LDS read per lane), columns = output channels (weights as the first operand: a lane holds 4 consecutive
+// channels of a voxel).  The 8 x 8 x 16 output brick is staged in LDS and leaves as whole 256-byte rows, with the BatchNorm statistics.
+struct TConv4Args {
+  const __bf16* x; const __bf16* w;   // x [I][D][H][W][32]; w packed forward [cout][64 taps][32] (tap = (kd*4 + kh)*4 + kw)
+  const float* bias; __bf16* out; double* stats; int cout; int I, D, H, W, nbricks;
+};
+constexpr int T4_JZ = 4, T4_JY = 4, T4_JX = 8, T4_HZ = 6, T4_HY = 6, T4_HX = 10, T4_HPOS = T4_HZ * T4_HY * T4_HX;
+
+__global__ __launch_bounds__(256, 2) void tconv4s2_fwd_kernel(const TConv4Args p) {
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[T4_HPOS * 32];            // halo brick [pos][32]
+  __shared__ __attribute__((aligned(16))) __bf16 Ws[8 * 8 * 256];             // [class][co][tap d*32 + c]
+  __shared__ __attribute__((aligned(16))) __bf16 Os[8 * 8 * 16 * 8];          // output brick [oz][oy][ox][8]
+  __shared__ float red[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  // class weights -> LDS: Ws[cls][co][t*32 + c] = w[co][tap(cls, t)][c]
+  for (int i = tid; i < 8 * 8 * 256 / 8; i += 256) {
+    const int c8 = (i & 3) * 8, t = (i >> 2) & 7, co = (i >> 5) & 7, cls = i >> 8;
+    const int az = cls >> 2, ay = (cls >> 1) & 1, ax = cls & 1, dz = t >> 2, dy = (t >> 1) & 1, dx = t & 1;
+    const int kz = az ? 2 - 2 * dz : 3 - 2 * dz, ky = ay ? 2 - 2 * dy : 3 - 2 * dy, kx = ax ? 2 - 2 * dx : 3 - 2 * dx;
+    bf16x8 v = VecN<__bf16, 8>::zero();
+    if (co < p.cout) v = *reinterpret_cast<const bf16x8*>(p.w + ((size_t)co * 64 + (kz * 4 + ky) * 4 + kx) * 32 + c8);
+    *reinterpret_cast<bf16x8*>(Ws + ((cls * 8 + co) * 256) + t * 32 + c8) = v;
+  }
+  float bias4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bias4[j] = (p.bias && lg < 2 && lg * 4 + j < p.cout) ? p.bias[lg * 4 + j] : 0.f;
+  double st1[8], st2[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { st1[c] = 0.0; st2[c] = 0.0; }
+  const int bz = p.D / T4_JZ, by = p.H / T4_JY, bx = p.W / T4_JX;
+  __syncthreads();
+  for (int brick = blockIdx.x; brick < p.nbricks; brick += gridDim.x) {
+    int t = brick;
+    const int x0 = (t % bx) * T4_JX; t /= bx;
+    const int y0 = (t % by) * T4_JY; t /= by;
+    const int z0 = (t % bz) * T4_JZ; const int img = t / bz;
+    // ---- halo brick -> LDS (zero outside the grid): 360 positions x 4 chunks of 8 channels
+    for (int i = tid; i < T4_HPOS * 4; i += 256) {
+      const int h = i >> 2, c8 = (i & 3) * 8;
+      const int hx = h % T4_HX; const int t2 = h / T4_HX; const int hy = t2 % T4_HY; const int hz = t2 / T4_HY;
+      const int z = z0 - 1 + hz, y = y0 - 1 + hy, xx = x0 - 1 + hx;
+      bf16x8 v = VecN<__bf16, 8>::zero();
+      if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+        v = *reinterpret_cast<const bf16x8*>(p.x + ((((size_t)img * p.D + z) * p.H + y) * p.W + xx) * 32 + c8);
+      *reinterpret_cast<bf16x8*>(Xs + h * 32 + c8) = v;
+    }
+    __syncthreads();
+    // ---- this wave: parity classes 2 wave, 2 wave + 1; 8 groups of 16 positions (jz, 2 jy rows, 8 jx) each
+    const int yy = lr >> 3, xx = lr & 7;
+#pragma unroll 1
+    for (int ci = 0; ci < 2; ++ci) {
+      const int cls = 2 * wave + ci, az = cls >> 2, ay = (cls >> 1) & 1, ax = cls & 1;
+      bf16x8 b[8];
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        b[tt] = VecN<__bf16, 8>::zero();
+        if (lr < 8) b[tt] = *reinterpret_cast<const bf16x8*>(Ws + (cls * 8 + lr) * 256 + tt * 32 + lg * 8);
+      }
+#pragma unroll 2
+      for (int g = 0; g < 8; ++g) {
+        const int jz = g >> 1, jy = (g & 1) * 2 + yy;
+        const int base = ((jz + az) * T4_HY + (jy + ay)) * T4_HX + (xx + ax);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          const int off = ((tt >> 2) * T4_HY + ((tt >> 1) & 1)) * T4_HX + (tt & 1);
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xs + (base + off) * 32 + lg * 8);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[tt], a, acc, 0, 0, 0);   // weights first: lane (lr, lg) holds voxel lr, channels 4 lg .. + 3
+        }
+        if (lg < 2) {
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (__bf16)(acc[j] + bias4[j]);
+          const int oz = 2 * jz + az, oy = 2 * jy + ay, ox = 2 * xx + ax;
+          *reinterpret_cast<bf16x4*>(Os + ((oz * 8 + oy) * 16 + ox) * 8 + lg * 4) = o;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- output brick -> HBM: 1024 voxels x 16 bytes, rows of 16 x-voxels contiguous; statistics of what is stored
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int v = tid + 256 * k;
+      const int ox = v & 15, oy = (v >> 4) & 7, oz = v >> 7;
+      const bf16x8 o = *reinterpret_cast<const bf16x8*>(Os + v * 8);
+      const size_t pos = (((size_t)img * (2 * p.D) + 2 * z0 + oz) * (2 * p.H) + 2 * y0 + oy) * (2 * p.W) + 2 * x0 + ox;
+      *reinterpret_cast<bf16x8*>(p.out + pos * 8) = o;
+      if (p.stats) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const double f = (double)(float)o[c]; st1[c] += f; st2[c] += f * f; }
+      }
+    }
+    __syncthreads();                                   // Xs / Os are rewritten by the next brick
+  }
+  if (p.stats) {   // per-channel sums: lanes -> waves -> one double atomic per channel and workgroup into one of SV_BN_SLOTS slot images
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float a = (float)st1[c], b2 = (float)st2[c];
+      a = wave_sum(a); b2 = wave_sum(b2);
+      if (lane == 0) { red[wave][c] = a; red[wave][8 + c] = b2; }
+    }
+    __syncthreads();
+    if (tid < 16 && (tid & 7) < p.cout) {
+      const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+      double* st = p.stats + (size_t)(blockIdx.x % SV_BN_SLOTS) * 2 * p.cout;
+      atomicAdd(st + (tid >> 3) * p.cout + (tid & 7), (double)v);
+    }
+  }
+}
+
 }  // namespace sv
 
 using namespace sv;
@@ -448,4 +566,17 @@ extern "C" int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int group
     else hipLaunchKernelGGL((stencil3_wgrad_kernel<3, AT>), dim3(blocks), dim3(256), 0, s, a););
   if (workspace) hipLaunchKernelGGL(stencil_wgrad_fold_kernel, dim3(cdiv(cout * cin * 27, 256)), dim3(256), 0, s, workspace, dw, cout * cin * 27);
   return check_launch("sv_stencil3_wgrad");
+}
+
+extern "C" int sv_tconv4s2_fwd(const void* x, const void* w_packed, const float* bias, void* out, double* stats, int I, int D, int H, int W,
+                               int cin, int cout, void* stream) {
+  SV_REQUIRE(x && w_packed && out && I > 0, "tconv4s2_fwd: null argument");
+  SV_REQUIRE(cin == 32 && cout > 0 && cout <= 8, "tconv4s2_fwd: built for 32 input and <= 8 output channels (got %d -> %d)", cin, cout);
+  SV_REQUIRE(D % T4_JZ == 0 && H % T4_JY == 0 && W % T4_JX == 0, "tconv4s2_fwd: input grid %dx%dx%d must be a multiple of the 4x4x8 brick", D, H, W);
+  SV_REQUIRE((((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out) & 15) == 0, "tconv4s2_fwd: operands must be 16-byte aligned");
+  TConv4Args a{static_cast<const __bf16*>(x), static_cast<const __bf16*>(w_packed), bias, static_cast<__bf16*>(out), stats, cout, I, D, H, W,
+               I * (D / T4_JZ) * (H / T4_JY) * (W / T4_JX)};
+  const int blocks = a.nbricks < 512 ? a.nbricks : 512;
+  hipLaunchKernelGGL(tconv4s2_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("sv_tconv4s2_fwd");
 }

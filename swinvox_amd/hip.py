@@ -64,6 +64,7 @@ _PROTOS = {
     "sv_stencil3_fwd": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _L, _L]),
     "sv_stencil3_wgrad_workspace_floats": (C.c_size_t, None, [_I, _I]),
     "sv_stencil3_wgrad": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _L]),
+    "sv_tconv4s2_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     "sv_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I]),
     "sv_pack_weights_block_elems": (_I, None),
     "sv_pack_weights": (_I, [_P, _I, _I, _I]),

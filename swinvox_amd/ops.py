@@ -210,11 +210,22 @@ class ConvSpec:
         call(name, *args)
         tr.end()
 
+    def _halo_tconv(self, in_grid, ldi, ldc, epi) -> bool:
+        return (self.transposed and self.k == (4, 4, 4) and self.s == (2, 2, 2) and self.p == (1, 1, 1) and self.cin == 32
+                and self.cin_mem == 32 and self.cout == 8 and _STATE["store"] == torch.bfloat16 and _STATE["math"] != hip.MATH_F32
+                and ldi in (None, 32) and ldc in (None, 8) and not (set(epi) - {"bias", "stats"})
+                and in_grid[0] % 4 == 0 and in_grid[1] % 4 == 0 and in_grid[2] % 8 == 0)
+
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x, n, in_grid, w_packed, out, *, ldi=None, ldc=None, **epi):
         og = self.out_grid(in_grid)
         if isinstance(w_packed, torch.nn.Parameter) or w_packed.dtype != _STATE["store"]:
             w_packed = self.pack_fwd(w_packed)     # raw parameter: pack / convert (identity for a Linear in fp32 storage)
+        if self._halo_tconv(in_grid, ldi, ldc, epi):
+            # k4 s2 p1, 32 -> 8 channels (decoder layer4): parity-class stencils on an LDS halo brick instead of L2 gathers
+            self._traced("sv_tconv4s2_fwd", n, in_grid, ptr(x), ptr(w_packed), ptr(epi.get("bias")), ptr(out), ptr(epi.get("stats")),
+                         n, *in_grid, self.cin, self.cout)
+            return og
         g = self._geom(n, in_grid, og, self.cin_mem, self.cout, ldi or self.cin_mem)
         e = _epilogue(ldc or self.cout, **epi)
         self._traced("sv_tconv_gather" if self.transposed else "sv_conv_gather", n, in_grid, ptr(x), ptr(w_packed), ptr(out),

@@ -171,6 +171,47 @@ def test_conv3d_family(dev, cin, cout, k, s, p, tr, D):
     assert rel(dw, w.grad) < TOL
 
 
+@pytest.mark.parametrize("n,D,bias", [(2, 8, True), (3, 16, False)])
+def test_tconv4s2_halo_brick(dev, n, D, bias):
+    """csrc/stencil.hip tconv4s2_fwd_kernel (decoder layer4: ConvTranspose3d 32 -> 8, k4 s2 p1 in bf16 storage) vs torch on bf16-rounded
+    operands; ConvSpec.forward must route to it, write the same rows as the generic engine and the BatchNorm sums of the stored values."""
+    ops.set_math("bf16"); ops.set_storage("bf16")
+    g = torch.Generator().manual_seed(40 + D)
+    bf = lambda t: t.bfloat16().float()
+    x = bf(torch.randn(n, 32, D, D, D, generator=g))
+    w = bf(torch.randn(32, 8, 4, 4, 4, generator=g) / math.sqrt(32 * 8))
+    b = torch.randn(8, generator=g) if bias else None
+    y = F.conv_transpose3d(x, w, b, stride=2, padding=1)
+    sp = ConvSpec.conv3d(32, 8, 4, 2, 1, transposed=True)
+    grid, M = (D, D, D), n * (2 * D) ** 3
+    assert sp._halo_tconv(grid, None, None, {"bias": None, "stats": None})
+    xd, wd = cl(x).to(dev).bfloat16().contiguous(), w.to(dev)
+    bd = b.to(dev) if bias else None
+    wp = sp.pack_fwd(wd)
+    out = torch.empty(M, 8, dtype=torch.bfloat16, device=dev)
+    stats = torch.zeros(ops.BN_SLOTS, 16, dtype=torch.float64, device=dev)
+    names = []
+    orig = ops.call
+    ops.call = lambda name, *a, **k: (names.append(name), orig(name, *a, **k))[1]
+    try:
+        sp.forward(xd, n, grid, wp, out, bias=bd, stats=stats)
+    finally:
+        ops.call = orig
+    assert names == ["sv_tconv4s2_fwd"]
+    ref = cl(y).reshape(M, 8)
+    assert rel(out.float(), ref) < 6e-3                        # one bf16 rounding of the stored value
+    st, o = stats.sum(0).cpu(), out.float().cpu().double()
+    assert rel(st[:8], o.sum(0)) < 1e-5 and rel(st[8:], (o * o).sum(0)) < 1e-5
+    # the generic engine on the same operands (what the layer ran through before): identical up to fp32 summation order
+    out2 = torch.empty(M, 8, dtype=torch.bfloat16, device=dev)
+    e = ops._epilogue(8, bias=bd)
+    gm = sp._geom(n, grid, sp.out_grid(grid), 32, 8, 32)
+    call("sv_tconv_gather", ptr(xd), ptr(wp), ptr(out2), C.byref(gm), C.byref(e), hip.MATH_BF16)
+    assert rel(out.float(), out2.float()) < 8e-3 and float((out.float() - out2.float()).abs().mean()) < 1e-4
+    with pytest.raises(RuntimeError, match="multiple of the 4x4x8 brick"):
+        call("sv_tconv4s2_fwd", ptr(xd), ptr(wp), None, ptr(out), None, n, D, D, 4, 32, 8)
+
+
 def test_padded_channel_conv3d_like_merger(dev):
     """9 real channels stored 12-wide; output written into a column slice of a 48-wide buffer."""
     g = torch.Generator().manual_seed(9)
