@@ -84,6 +84,9 @@ typedef struct sv_epilogue {
  * gather form:  out[o, co] = sum_{tap,ci} in[o*s - p + tap, ci] * w[co, tap, ci]      (conv forward; tconv data-grad; Linear) */
 int sv_conv_gather(const void* in, const void* w_packed, void* out, const sv_geom* g, const sv_epilogue* e,
                    int math, int act_dtype, void* stream);
+/* 1 when sv_conv_gather would run this call on the wide dense kernel (256 x 128 tile, LDS-DMA operand ring: Linear / 1x1 layers with
+ * bf16 storage, K % 32 == 0, K >= 128, Co >= 128, 8-aligned rows and >= 256 tiles), else 0.  SV_GEMM_WIDE=0 in the environment disables it. */
+int sv_conv_gather_is_wide(const void* in, const void* w, void* out, const sv_geom* g, const sv_epilogue* e, int math, int act_dtype);
 /* scatter-as-gather form: out[o, co] = sum_{tap,ci : (o+p-tap)%s==0} in[(o+p-tap)/s, ci] * w[co, tap, ci]
  * (transposed-conv forward; strided-conv data-grad), decomposed per output parity class            */
 int sv_tconv_gather(const void* in, const void* w_packed, void* out, const sv_geom* g, const sv_epilogue* e,

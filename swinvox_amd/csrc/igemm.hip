@@ -17,6 +17,7 @@
 // (register-staged: the gather needs per-element predication and an fp32->bf16 conversion).
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace sv {
 
@@ -600,6 +601,279 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR >= 512 ? 4 : 2) void gemm_dense_
 }
 
 // ------------------------------------------------------------------------------------------------
+// wide dense kernel (bf16 MFMA, bf16 storage) for the deep / wide Linear and 1x1 layers (Swin stages 2-3, ResNet layer 3 1x1s).
+// Measured on these shapes (scripts/bench_gemm_wide.py with the SV_GW_PROBE_* builds, scripts/probes/dma_fill_probe.hip): the MFMA + LDS
+// part of a 256 x 128 tile runs at ~1.2 PFLOP/s, and what bounds the layer is the L2 -> LDS operand fill: 43-57 GB/s per CU when a wave
+// instruction fetches 16 rows x 64 B, 62-84 GB/s with 8 rows x 128 B (whole cache lines) and >= 96 KB in flight per CU.  Hence:
+//   * one workgroup per CU owns a 256 x 128 tile: 8 consumer waves (4 x 2, 64 x 64 each; 1.33 x fewer staged bytes per MAC than
+//     128 x 128) and 4 producer waves, one per SIMD, that do nothing but issue the operand DMA - an LDS-DMA instruction blocks its wave
+//     while the memory pipeline is backed up, and in the consumers' instruction stream that wait would stall the MFMAs behind it
+//     (measured: fill alone 106 us, MFMA alone 110 us, both from one instruction stream 174 us on M = 25088, K = 3072, N = 768);
+//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write) in 64-deep K slices - every
+//     row piece is one whole 128-byte line - into a ring of three 48 KB slots; slice s + 2 is issued right after the barrier of slice
+//     s, so two slices (96 KB) are in flight behind the MFMAs (counted vmcnt in the producers, raw s_barrier);
+//   * the workgroup is persistent and the slice stream runs ACROSS tiles: the first two slices of the next tile are issued under the
+//     last two of the current one, so the DMA queue never runs dry at a tile boundary or during an epilogue;
+//   * the epilogue works on the accumulator registers (lane = one row, 4 consecutive columns per 16 x 16 block) - no LDS, no barrier;
+//     one barrier per K slice is all the synchronisation there is.
+// LDS image of a slice: rows of 64 bf16 (128 B = eight 16-byte slots), a DMA piece = 8 rows (lane l -> row l / 8, slot l % 8); the
+// source chunk of (row r, slot s) is s ^ (r / 2 mod 8): with that XOR the four 16-lane groups of a ds_read_b128 fragment read (16
+// rows, k chunk = 4 ks + lane / 16) each touch 16 different bank slots (MI355X_MICROARCH.md, LDS).
+// Epilogue semantics = epilogue_rows (bias / activation(-gradient) / residual / pre-activation copy / statistics).
+// Host-side conditions: K % 64 == 0, K >= 192, 8-aligned rows and columns (gemm_wide_ok).
+// ------------------------------------------------------------------------------------------------
+constexpr int GW_BM = 256, GW_BN = 128, GW_BK = 64, GW_STAGES = 3;
+constexpr int GW_NCONS = 8, GW_NPROD = 4, GW_NTHR = (GW_NCONS + GW_NPROD) * 64;
+constexpr int GW_A_BYTES = GW_BM * GW_BK * 2, GW_STAGE_BYTES = (GW_BM + GW_BN) * GW_BK * 2;   // 32 KB + 16 KB
+typedef __attribute__((address_space(1))) const void* gw_gptr_t;
+typedef __attribute__((address_space(3))) void* gw_lptr_t;
+
+// GENERAL = the epilogue reads a residual and / or an activation-gradient source; false = bias / activation / pre-activation copy / statistics
+template <bool GENERAL>
+__global__ __launch_bounds__(GW_NTHR, 3) void gemm_wide_kernel(const IGemmArgs p, int ntiles, int* __restrict__ ctr) {
+  // ONE object (a second one makes hipcc drain the DMA queue): the ring + the two-word mailbox of the tile scheduler
+  __shared__ __attribute__((aligned(1024))) char smem[GW_STAGES * GW_STAGE_BYTES + 64];
+  const __bf16* __restrict__ X = static_cast<const __bf16*>(p.x);
+  const __bf16* __restrict__ Wt = static_cast<const __bf16*>(p.w);
+  __bf16* __restrict__ Y = static_cast<__bf16*>(p.y);
+  const Geom& g = p.g;
+  const Epi& e = p.e;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Mrows = g.N * g.Do * g.Ho * g.Wo, K = g.Ci, nk = K / GW_BK;
+  const int tiles_n = (g.Co + GW_BN - 1) / GW_BN;
+  // ---- tile scheduler.  Tiles are handed out at run time: with a static share per workgroup a workgroup that gets its CU late (another
+  // stream's kernel holds the LDS) makes the whole launch wait for its share (measured beside the ResNet branch: launches of 0.2 ms
+  // stretched to 2.6 ms).  The tile space is cut into 8 contiguous chunks, one per XCD (workgroups b, b + 8, ... share an L2, and
+  // consecutive tiles share an activation row panel); ctr[x] counts the tiles of chunk x handed out, ctr[8] the workgroups that are done -
+  // the last one zeroes the counters for the launch that uses this slot next.  Producer 0 draws the next tile while the current one runs
+  // and posts it in the mailbox (two words, by tile parity); everyone reads it behind the barrier of the second K slice.
+  const int xcd = blockIdx.x & 7, cq = ntiles >> 3, cr = ntiles & 7;
+  const int cbase = xcd * cq + (xcd < cr ? xcd : cr), csize = cq + (xcd < cr ? 1 : 0);
+  typedef __attribute__((address_space(3))) int lds_int;   // explicit LDS pointer: a generic (flat) access would be waited for with vmcnt(0)
+  lds_int* mbox = (lds_int*)(smem + GW_STAGES * GW_STAGE_BYTES);
+  if (tid == 0) {
+    const int v = atomicAdd(ctr + xcd, 1);
+    mbox[0] = v < csize ? cbase + v : -1;
+  }
+  __syncthreads();
+  int tcur = mbox[0], tnext = -1, it = 0;
+  int row0 = (tcur / tiles_n) * GW_BM, col0 = (tcur % tiles_n) * GW_BN, row0n = 0, col0n = 0;
+  auto finish = [&]() {   // one thread per workgroup, after its last draw
+    if (atomicAdd(ctr + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) ctr[i] = 0;
+    }
+  };
+  if (tcur < 0) { if (tid == 0) finish(); return; }
+
+  if (wave >= GW_NCONS) {
+    // ================= producer wave pw: A pieces 8 pw .. 8 pw + 7, W pieces 4 pw .. 4 pw + 3 of every slice =================
+    // lane l of piece q = row 8 q + l / 8, slot l % 8 <- chunk (l % 8) ^ (row / 2 mod 8) = (l % 8) ^ (4 (q & 1) | l / 16)
+    const int pw = wave - GW_NCONS;
+    const int chunk0 = (lane & 7) ^ (lane >> 4);
+    const __bf16* pa[8];
+    const __bf16* pb[4];
+    auto set_sources = [&](int r0, int c0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int m = r0 + (pw * 8 + i) * 8 + (lane >> 3);
+        if (m >= Mrows) m = Mrows - 1;                     // rows past the end: any valid row, the epilogue skips them
+        pa[i] = X + (size_t)m * g.ldi + (chunk0 ^ ((i & 1) << 2)) * 8;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int n = c0 + (pw * 4 + i) * 8 + (lane >> 3);
+        if (n >= g.Co) n = g.Co - 1;
+        pb[i] = Wt + (size_t)n * p.Ktot + (chunk0 ^ ((i & 1) << 2)) * 8;
+      }
+    };
+    auto issue = [&](int kt, int st) {
+#ifdef SV_GW_PROBE_NODMA
+      return;
+#endif
+      char* base = smem + st * GW_STAGE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((gw_gptr_t)(pa[i] + kt * GW_BK), (gw_lptr_t)(base + (pw * 8 + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((gw_gptr_t)(pb[i] + kt * GW_BK), (gw_lptr_t)(base + GW_A_BYTES + (pw * 4 + i) * 1024), 16, 0, 0);
+    };
+    set_sources(row0, col0);
+    issue(0, 0);
+    issue(1, 1);                                          // nk >= 3
+    int st = 0;
+    bool have = true;
+    while (have) {
+      bool more = true;                                   // known from the second slice on (nk >= 3: the last slice is a later one)
+      unsigned drawn = 0;
+      for (int kt = 0; kt < nk; ++kt) {
+        // this wave's pieces of the slice have landed (the 12 of the next slice may stay in flight); behind the barrier every
+        // producer's have, and every consumer is done reading the previous slice, whose ring slot the slice after next overwrites
+        if (kt + 1 < nk || more) asm volatile("s_waitcnt vmcnt(12)" : "+v"(drawn) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn) :: "memory");
+        if (kt == 1 && pw == 0 && lane == 0) {            // the draw of slice 0 is older than the 12 pieces waited past: it has returned
+          const int v = (int)drawn;
+          mbox[(it + 1) & 1] = v < csize ? cbase + v : -1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt == 1) {
+          tnext = mbox[(it + 1) & 1];
+          more = tnext >= 0;
+          row0n = (tnext / tiles_n) * GW_BM; col0n = (tnext % tiles_n) * GW_BN;
+        }
+        if (kt == 0 && pw == 0 && lane == 0)              // draw the next tile: an atomic hipcc does not count (it would drain the DMA queue for it)
+          asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(ctr + xcd), "v"(1u) : "memory");
+        const int st2 = st == 0 ? 2 : st - 1;
+        if (kt + 2 < nk) issue(kt + 2, st2);
+        else if (more) {
+          if (kt + 2 == nk) set_sources(row0n, col0n);   // the current tile's last slice was issued an iteration ago
+          issue(kt + 2 - nk, st2);
+        }
+        st = st == 2 ? 0 : st + 1;
+      }
+      have = more; ++it;
+    }
+    return;
+  }
+
+  // ================= consumer waves: 4 x 2 grid of 64 x 64 wave tiles =================
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lg = lane >> 4;
+  // fragment addresses: row lr of a 16-row block, k chunk 4 ks + lg -> slot (4 ks + lg) ^ (lr / 2)
+  int aoff[2], boff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int slot = (ks * 4 + lg) ^ (lr >> 1);
+    aoff[ks] = (wm * 64 + lr) * 128 + slot * 16;
+    boff[ks] = GW_A_BYTES + (wn * 64 + lr) * 128 + slot * 16;
+  }
+  int st = 0;                                             // ring slot of the slice computed next
+  bool have = true;
+  while (have) {
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_barrier" ::: "memory");             // the slice has landed (the producers waited for it before this barrier)
+      if (kt == 1) tnext = mbox[(it + 1) & 1];            // posted by producer 0 in front of this barrier
+#ifndef SV_GW_PROBE_NOMMA
+      const char* sb = smem + st * GW_STAGE_BYTES;
+      bf16x8 a[2][4], b[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) b[ks][nt] = *reinterpret_cast<const bf16x8*>(sb + boff[ks] + nt * 2048);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a[ks][mt] = *reinterpret_cast<const bf16x8*>(sb + aoff[ks] + mt * 2048);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ks][nt], a[ks][mt], acc[mt][nt], 0, 0, 0);
+#endif
+      st = st == 2 ? 0 : st + 1;
+    }
+
+    // ---- epilogue on the registers: lane (lr, lg) of block (mt, nt) = row mt * 16 + lr, columns nt * 16 + lg * 4 .. + 3.
+    // Every global LOAD of the tile (row scales, residual, activation-gradient source) is issued before the first STORE: vmcnt retires
+    // in issue order, so a load behind stores could only be waited for by draining the stores (measured: ~2 us per 16-row block).
+    {
+      const int mbase = row0 + wm * 64 + lr, nbase = col0 + wn * 64 + lg * 4;
+      bool colok[4];
+      float bias[4][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        colok[nt] = nbase + nt * 16 < g.Co;                // Co % 8 == 0: a 4-vector is whole or absent
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias[nt][j] = (e.bias && colok[nt]) ? e.bias[nbase + nt * 16 + j] : 0.f;
+      }
+      float rsc[4];
+      bf16x4 aux[4][4];                                    // residual OR activation-gradient source (gemm_wide_ok: never both)
+      if constexpr (GENERAL) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int m = mbase + mt * 16;
+          const bool rowok = m < Mrows;
+          rsc[mt] = (rowok && e.residual && e.row_scale) ? e.row_scale[m / e.rows_per_scale] : 1.f;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const int n0 = nbase + nt * 16;
+            aux[mt][nt] = VecN<__bf16, 4>::zero();
+            if (rowok && colok[nt]) {
+              const __bf16* src = e.residual ? static_cast<const __bf16*>(e.residual) + (size_t)m * e.ldr + n0
+                                             : static_cast<const __bf16*>(e.act_grad_src) + (size_t)m * e.ldc + e.col_off + n0;
+              aux[mt][nt] = *reinterpret_cast<const bf16x4*>(src);
+            }
+          }
+        }
+      }
+      float s1[4][4], s2[4][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[nt][j] = 0.f; s2[nt][j] = 0.f; }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int m = mbase + mt * 16;
+        if (m < Mrows) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            if (colok[nt]) {
+              float v[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j] + bias[nt][j];
+              const size_t o = (size_t)m * e.ldc + e.col_off + nbase + nt * 16;
+              if constexpr (GENERAL) {
+                if (e.act_grad_src) {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) v[j] *= act_grad_t<true>((float)aux[mt][nt][j], e.act_grad_kind, e.slope);
+                }
+              }
+              if (e.pre_act) stnf<4>(static_cast<__bf16*>(e.pre_act) + o, v);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = apply_act_t<true>(v[j], e.act, e.slope);
+              if constexpr (GENERAL) {
+                if (e.residual) {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) v[j] = (float)aux[mt][nt][j] + rsc[mt] * v[j];
+                }
+              }
+#ifdef SV_GW_PROBE_NOSTORE
+              if (v[0] == 1234.5f)
+#endif
+              stnf<4>(Y + o, v);
+              if constexpr (!GENERAL) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s1[nt][j] += v[j]; s2[nt][j] += v[j] * v[j]; }
+              }
+            }
+          }
+        }
+      }
+      if (!GENERAL && e.stats) {   // (gemm_wide_ok: statistics never come with a residual / activation-gradient source) the 16 rows of a lane group, then one double atomic per column and wave (64 rows) into a slot image
+        double* stp = e.stats + (size_t)((row0 / 64 + wm) % SV_BN_SLOTS) * 2 * g.Co;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float a1 = s1[nt][j], a2 = s2[nt][j];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+            const int n = nbase + nt * 16 + j;
+            if (lr == 0 && n < g.Co) { atomicAdd(stp + n, (double)a1); atomicAdd(stp + g.Co + n, (double)a2); }
+          }
+      }
+    }
+    have = tnext >= 0; row0 = (tnext / tiles_n) * GW_BM; col0 = (tnext % tiles_n) * GW_BN; ++it;
+  }
+  if (tid == 0) finish();
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight-gradient kernel
 // ------------------------------------------------------------------------------------------------
 struct WGradArgs {
@@ -882,6 +1156,40 @@ static int check_common(const sv_geom* g, const sv_epilogue* e, const void* in, 
   return SV_OK;
 }
 
+// scheduler counters of the wide kernel: 16 ints per launch slot, zero on entry, zeroed again by the launch's last workgroup.  A slot is
+// reused after GW_SLOTS launches of this process - far more than a device queue holds in flight.
+constexpr int GW_SLOTS = 4096;
+static int* gemm_wide_counters();
+static bool gemm_wide_counters_ready() { static const bool ok = gemm_wide_counters() != nullptr; return ok; }
+static int* gemm_wide_counters() {
+  static int* buf = [] {
+    int* b = nullptr;
+    if (hipMalloc(&b, sizeof(int) * 16 * GW_SLOTS) != hipSuccess || hipMemset(b, 0, sizeof(int) * 16 * GW_SLOTS) != hipSuccess) return (int*)nullptr;
+    hipDeviceSynchronize();
+    return b;
+  }();
+  static std::atomic<unsigned> next{0};
+  return buf ? buf + 16 * (next.fetch_add(1) % GW_SLOTS) : nullptr;
+}
+
+// the wide kernel takes the dense layers whose K loop is worth a DMA ring and whose tile count fills the chip;
+// SV_GEMM_WIDE=0 in the environment keeps every layer on the 128-wide kernels (A/B measurements)
+static bool gemm_wide_ok(const IGemmArgs& a, long long M) {
+  static const int enabled = [] { const char* v = getenv("SV_GEMM_WIDE"); return v ? atoi(v) : 1; }();
+  const Epi& e = a.e;
+  const int K = a.g.Ci, Co = a.g.Co;
+  if (!enabled || K % GW_BK || K < 3 * GW_BK || Co < 128 || a.Ktot % 8) return false;
+  // where it wins (scripts/bench_gemm_wide.py, M = 25k .. 400k): deep K; short K only with many output columns; BatchNorm producers
+  // (two double atomics per column and 64 rows) only when the K loop is long enough to carry them
+  if (enabled == 1 && !(K >= 384 || (K >= 192 && Co >= 384))) return false;
+  if (enabled == 1 && e.stats && K < 1024) return false;
+  if (((e.ldc | e.col_off | Co) & 7) || (e.residual && (e.ldr & 7))) return false;
+  // the general epilogue variant keeps no statistics registers and one set of prefetched rows (residual OR activation-gradient source)
+  if ((e.stats && (e.residual || e.act_grad_src)) || (e.residual && e.act_grad_src)) return false;
+  if (((uintptr_t)a.y | (uintptr_t)e.residual | (uintptr_t)e.pre_act | (uintptr_t)e.act_grad_src | (uintptr_t)a.w) & 15) return false;
+  return (long long)cdiv(M, GW_BM) * cdiv(Co, GW_BN) >= 256;
+}
+
 template <bool TCONV>
 static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, int act, hipStream_t s) {
   const int Co = a.g.Co;
@@ -917,6 +1225,13 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, in
     hipLaunchKernelGGL((gemm_dense_kernel<TL, __bf16, __bf16, 8>), dim3(nb), dim3(TL::NTHR), 0, s, a, ntiles);      \
   } while (0)
   if constexpr (!TCONV) {
+    if (dense && gemm_wide_ok(a, M) && gemm_wide_counters_ready()) {
+      const int ntiles = cdiv(M, GW_BM) * cdiv(Co, GW_BN);
+      int* ctr = gemm_wide_counters();
+      if (a.e.residual || a.e.act_grad_src) hipLaunchKernelGGL(gemm_wide_kernel<true>, dim3(256), dim3(GW_NTHR), 0, s, a, ntiles, ctr);
+      else hipLaunchKernelGGL(gemm_wide_kernel<false>, dim3(256), dim3(GW_NTHR), 0, s, a, ntiles, ctr);
+      return;
+    }
     if (dense && Co > 16) {
       if (use96) SV_LAUNCH_DENSE(Tile96);
       else if (Co > 64 && (long long)cdiv(M, 128) * cdiv(Co, 128) >= 384) SV_LAUNCH_DENSE(TileBig);
@@ -960,6 +1275,19 @@ extern "C" int sv_conv_gather(const void* in, const void* w, void* out, const sv
   const long long M = (long long)g->N * g->Do * g->Ho * g->Wo;
   launch_igemm<false>(a, M, 1, math, act_dtype, (hipStream_t)stream);
   return check_launch("sv_conv_gather");
+}
+
+/* 1 when sv_conv_gather would run this call on the wide (256 x 128, LDS-DMA ring) kernel, 0 for the 128-wide kernels; tests use it
+ * to make sure they exercise the path they mean to. */
+extern "C" int sv_conv_gather_is_wide(const void* in, const void* w, void* out, const sv_geom* g, const sv_epilogue* e, int math, int act_dtype) {
+  if (!g || !e || math != SV_MATH_BF16 || act_dtype != SV_BF16) return 0;
+  IGemmArgs a{};
+  a.x = in; a.w = w; a.y = out; a.g = to_geom(g); a.e = to_epi(e);
+  a.Ktot = g->kd * g->kh * g->kw * g->Ci;
+  const bool v8 = (a.g.Ci % 8) == 0 && (a.g.ldi % 8) == 0 && ((uintptr_t)a.x & 15) == 0;
+  const bool dense = v8 && a.g.kd * a.g.kh * a.g.kw == 1 && a.g.sd == 1 && a.g.sh == 1 && a.g.sw == 1 &&
+                     a.g.pd == 0 && a.g.ph == 0 && a.g.pw == 0 && a.g.Di == a.g.Do && a.g.Hi == a.g.Ho && a.g.Wi == a.g.Wo;
+  return dense && gemm_wide_ok(a, (long long)g->N * g->Do * g->Ho * g->Wo) ? 1 : 0;
 }
 
 extern "C" int sv_tconv_gather(const void* in, const void* w, void* out, const sv_geom* g, const sv_epilogue* e,

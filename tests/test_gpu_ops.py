@@ -98,6 +98,68 @@ def test_linear_bf16_math(dev):
     assert rel(dw, dy.bfloat16().float().t() @ x.bfloat16().float()) < 2e-3
 
 
+def _is_wide(sp, x, n, grid, wp, out, **epi):
+    og = sp.out_grid(grid)
+    gm = sp._geom(n, grid, og, sp.cin_mem, sp.cout, sp.cin_mem)
+    e = ops._epilogue(epi.pop("ldc", sp.cout), **epi)
+    return hip.load().sv_conv_gather_is_wide(ptr(x), ptr(wp), ptr(out), C.byref(gm), C.byref(e), hip.MATH_BF16, hip.BF16)
+
+
+@pytest.mark.parametrize("mode", ["plain", "bias_gelu_preact", "residual_scale", "act_grad", "stats", "column_slice"])
+def test_gemm_wide_kernel(dev, mode):
+    """csrc/igemm.hip gemm_wide_kernel (256 x 128 tile, LDS-DMA ring; the deep Linear / 1x1 layers in bf16 storage) against torch on
+    bf16-rounded operands, with ragged rows (M % 256 != 0), ragged columns (Co % 128 != 0) and every epilogue feature of the engine."""
+    ops.set_math("bf16"); ops.set_storage("bf16")
+    g = torch.Generator().manual_seed(77)
+    M, K, N = 256 * 130 + 37, (1024 if mode == "stats" else 384), 392   # (the kernel takes BatchNorm producers from K = 1024 on)
+    bf = lambda t: t.bfloat16().float()
+    x, w = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g)
+    acc = x @ w.t()
+    sp = ConvSpec.linear(K, N)
+    xd, wp = x.to(dev).bfloat16(), sp.pack_fwd(w.to(dev))
+    bd = b.to(dev)
+    ldc, off = (N, 0) if mode != "column_slice" else (N + 24, 16)
+    out = torch.zeros(M, ldc, dtype=torch.bfloat16, device=dev)
+    epi, ref, extra = {}, acc, None
+    if mode == "bias_gelu_preact":
+        pre = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        epi = dict(bias=bd, act=ACT_GELU, pre_act=pre)
+        ref = F.gelu(acc + b)
+        extra = (pre, acc + b)
+    elif mode == "residual_scale":
+        res = bf(torch.randn(M, N, generator=g))
+        scale = torch.rand(M // 49 + 1, generator=g)
+        epi = dict(bias=bd, residual=keep(res.to(dev).bfloat16()), ldr=N, row_scale=keep(scale.to(dev)), rows_per_scale=49)
+        ref = res + scale[torch.arange(M) // 49, None] * (acc + b)
+    elif mode == "act_grad":
+        src = bf(torch.randn(M, N, generator=g))
+        epi = dict(act_grad_src=keep(src.to(dev).bfloat16()), act_grad_kind=ACT_RELU)
+        ref = acc * (src > 0)
+    elif mode == "stats":
+        stats = torch.zeros(ops.BN_SLOTS, 2 * N, dtype=torch.float64, device=dev)
+        epi = dict(bias=bd, stats=stats)
+        ref = acc + b
+    assert _is_wide(sp, xd, M, (1, 1, 1), wp, out[:, off:], ldc=ldc, **epi) == 1
+    sp.forward(xd, M, (1, 1, 1), wp, out[:, off:], ldc=ldc, **epi)
+    got = out[:, off:off + N].float()
+    assert rel(got, ref) < 6e-3 and float((got.cpu() - ref).abs().mean()) < 2e-3 * float(ref.abs().mean() + 1)
+    if mode == "column_slice":
+        assert float(out[:, :off].abs().max()) == 0 and float(out[:, off + N:].abs().max()) == 0
+    if extra is not None:
+        assert rel(extra[0].float(), extra[1]) < 6e-3
+    if mode == "stats":
+        st, o = stats.sum(0).cpu(), got.cpu().double()
+        assert rel(st[:N], o.sum(0)) < 1e-4 and rel(st[N:], (o * o).sum(0)) < 1e-4
+    # K not a multiple of the 64-deep slice, short K with few columns and small problems stay on the 128-wide kernels
+    sp2 = ConvSpec.linear(K + 32, N)
+    x2 = torch.zeros(M, K + 32, dtype=torch.bfloat16, device=dev)
+    assert _is_wide(sp2, x2, M, (1, 1, 1), sp2.pack_fwd(torch.zeros(N, K + 32, device=dev)), out[:, off:], ldc=ldc) == 0
+    assert _is_wide(sp, xd[:4096], 4096, (1, 1, 1), wp, out[:4096, off:], ldc=ldc) == 0
+    sp3 = ConvSpec.linear(192, 264)
+    assert _is_wide(sp3, xd, M, (1, 1, 1), sp3.pack_fwd(torch.zeros(264, 192, device=dev)), out[:, off:], ldc=ldc) == 0
+
+
 CONV2D = [  # cin, cout, k, s, p, H
     (64, 64, 3, 1, 1, 14), (256, 256, 3, 2, 1, 14), (64, 128, 1, 2, 0, 14), (3, 64, 7, 2, 3, 32), (3, 96, 4, 4, 0, 32), (512, 256, 3, 1, 1, 7)]
 
