@@ -631,8 +631,9 @@ typedef __attribute__((address_space(3))) void* gw_lptr_t;
 // GENERAL = the epilogue reads a residual and / or an activation-gradient source; false = bias / activation / pre-activation copy / statistics
 template <bool GENERAL>
 __global__ __launch_bounds__(GW_NTHR, 3) void gemm_wide_kernel(const IGemmArgs p, int ntiles, int* __restrict__ ctr) {
-  // ONE object (a second one makes hipcc drain the DMA queue): the ring + the two-word mailbox of the tile scheduler
-  __shared__ __attribute__((aligned(1024))) char smem[GW_STAGES * GW_STAGE_BYTES + 64];
+  // ONE object (a second one makes hipcc drain the DMA queue): the ring + the two-word mailbox of the tile scheduler + a 1 KB store patch
+  // per consumer wave
+  __shared__ __attribute__((aligned(1024))) char smem[GW_STAGES * GW_STAGE_BYTES + 64 + GW_NCONS * 1024];
   const __bf16* __restrict__ X = static_cast<const __bf16*>(p.x);
   const __bf16* __restrict__ Wt = static_cast<const __bf16*>(p.w);
   __bf16* __restrict__ Y = static_cast<__bf16*>(p.y);
@@ -816,43 +817,68 @@ __global__ __launch_bounds__(GW_NTHR, 3) void gemm_wide_kernel(const IGemmArgs p
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s1[nt][j] = 0.f; s2[nt][j] = 0.f; }
+      // stores: a lane holds 8 bytes of a row; through a wave-private 8-row x 128-byte LDS patch (16-byte pairs XOR-swizzled by the row:
+      // conflict-free both ways) they become 16 bytes per lane, 8 whole 128-byte rows per instruction - a quarter of the cache lines
+      // touched per byte of the 8-byte form (measured: the partial-line stores cost as much as the K loop at K = 384)
+      typedef __attribute__((address_space(3))) char lds_char;
+      lds_char* stg = (lds_char*)(smem + GW_STAGES * GW_STAGE_BYTES + 64) + wave * 1024;
+      const int wrow = lr & 7, half_of_lane = lr >> 3, rrow = lane >> 3;
+      const int roff = rrow * 128 + (((lane & 7) ^ rrow) << 4);
+      const int ncol_s = col0 + wn * 64 + (lane & 7) * 8;
+      auto rows_out = [&](__bf16* dst, const bf16x4 (&ob)[4], int mt) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (half_of_lane == h) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+              *reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(stg + wrow * 128 + (((nt * 4 + lg) ^ (2 * wrow)) << 3)) = ob[nt];
+          }
+          __builtin_amdgcn_wave_barrier();
+          const bf16x8 o16 = *reinterpret_cast<__attribute__((address_space(3))) bf16x8*>(stg + roff);
+          __builtin_amdgcn_wave_barrier();
+          const int ms = row0 + wm * 64 + mt * 16 + h * 8 + rrow;
+#ifdef SV_GW_PROBE_NOSTORE
+          if (o16[0] == (__bf16)1234.5f)
+#endif
+          if (ms < Mrows && ncol_s < g.Co) *reinterpret_cast<bf16x8*>(dst + (size_t)ms * e.ldc + e.col_off + ncol_s) = o16;
+        }
+      };
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const int m = mbase + mt * 16;
-        if (m < Mrows) {
+        const bool rowok = mbase + mt * 16 < Mrows;
+        bf16x4 ob[4], pb[4];
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            if (colok[nt]) {
-              float v[4];
+        for (int nt = 0; nt < 4; ++nt) {
+          float v[4];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j] + bias[nt][j];
-              const size_t o = (size_t)m * e.ldc + e.col_off + nbase + nt * 16;
-              if constexpr (GENERAL) {
-                if (e.act_grad_src) {
+          for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j] + bias[nt][j];
+          if constexpr (GENERAL) {
+            if (e.act_grad_src) {
 #pragma unroll
-                  for (int j = 0; j < 4; ++j) v[j] *= act_grad_t<true>((float)aux[mt][nt][j], e.act_grad_kind, e.slope);
-                }
-              }
-              if (e.pre_act) stnf<4>(static_cast<__bf16*>(e.pre_act) + o, v);
+              for (int j = 0; j < 4; ++j) v[j] *= act_grad_t<true>((float)aux[mt][nt][j], e.act_grad_kind, e.slope);
+            }
+          }
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = apply_act_t<true>(v[j], e.act, e.slope);
-              if constexpr (GENERAL) {
-                if (e.residual) {
+          for (int j = 0; j < 4; ++j) pb[nt][j] = (__bf16)v[j];
 #pragma unroll
-                  for (int j = 0; j < 4; ++j) v[j] = (float)aux[mt][nt][j] + rsc[mt] * v[j];
-                }
-              }
-#ifdef SV_GW_PROBE_NOSTORE
-              if (v[0] == 1234.5f)
-#endif
-              stnf<4>(Y + o, v);
-              if constexpr (!GENERAL) {
+          for (int j = 0; j < 4; ++j) v[j] = apply_act_t<true>(v[j], e.act, e.slope);
+          if constexpr (GENERAL) {
+            if (e.residual) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { s1[nt][j] += v[j]; s2[nt][j] += v[j] * v[j]; }
-              }
+              for (int j = 0; j < 4; ++j) v[j] = (float)aux[mt][nt][j] + rsc[mt] * v[j];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ob[nt][j] = (__bf16)v[j];
+          if constexpr (!GENERAL) {
+            if (rowok && colok[nt]) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { const float f = (float)ob[nt][j]; s1[nt][j] += f; s2[nt][j] += f * f; }
             }
           }
         }
+        if (e.pre_act) rows_out(static_cast<__bf16*>(e.pre_act), pb, mt);
+        rows_out(Y, ob, mt);
       }
       if (!GENERAL && e.stats) {   // (gemm_wide_ok: statistics never come with a residual / activation-gradient source) the 16 rows of a lane group, then one double atomic per column and wave (64 rows) into a slot image
         double* stp = e.stats + (size_t)((row0 / 64 + wm) % SV_BN_SLOTS) * 2 * g.Co;
