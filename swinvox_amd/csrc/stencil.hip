@@ -16,6 +16,7 @@
 #include "common.h"
 #include <map>
 #include <mutex>
+#include <type_traits>
 
 namespace sv {
 
@@ -47,28 +48,42 @@ __device__ __forceinline__ TileId tile_of(int t, int D, int H, int W) {
   return r;
 }
 
-// one thread's share of a halo brick [HPOS][16*G], kept as raw 4-element vectors between the prefetch and the LDS store
+// one thread's share of a halo brick [HPOS][16*G], kept as raw 4-element vectors between the prefetch and the LDS store.
+// What does not depend on the brick is worked out ONCE per thread (init): the element offset of every vector from the brick's
+// corner and which faces of the halo box it lies on.  A brick then costs, per vector, one AND + compare (does a face it lies on stick
+// out of the volume?), one 64-bit add and the load - the div / mod chains and 64-bit multiplies that used to run per vector and brick
+// were the bulk of the kernel's instructions (the 9 -> 9 forward: 3,000 instructions around 8 MFMAs).
 template <int G, typename AT>
 struct HaloRegs {
   static constexpr int C = 16 * G, VPP = C / 4, N = (HPOS * VPP + 255) / 256;
+  typedef typename std::conditional<G == 1, int, long long>::type OffT;   // planes (G > 1) can lie > 2^31 elements apart
   typename V4<AT>::type r[N];
+  OffT off[N];      // element offset from the brick's corner position (z0 - 1, y0 - 1, x0 - 1), channel / plane offset included
+  int face[N];      // bit 0 / 1: on the z-low / z-high face of the halo box, 2 / 3: y, 4 / 5: x; bit 6: never loaded
   // plane == 0: position rows of ldx channels; plane != 0: the channels are stored as planes of ldx channels each
   // (memory channel c at x[(c / ldx) * plane + pos * ldx + c % ldx]) - the dense per-layer buffers of the merger's concat
-  __device__ __forceinline__ void load(const AT* __restrict__ x, int ldx, long long plane, int cin_load, const TileId& t, int D, int H, int W, int tid) {
+  __device__ __forceinline__ void init(int ldx, long long plane, int cin_load, int H, int W, int tid) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const int i = tid + 256 * k;
+      const int h = i / VPP, v = i - h * VPP;
+      const int hx = h % HX; const int t2 = h / HX; const int hy = t2 % HY; const int hz = t2 / HY;
+      const int cv = v * 4, pl = plane ? cv / ldx : 0;
+      face[k] = (hz == 0 ? 1 : 0) | (hz == HZ - 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == HY - 1 ? 8 : 0) | (hx == 0 ? 16 : 0) | (hx == HX - 1 ? 32 : 0) |
+                ((i < HPOS * VPP && cv < cin_load) ? 0 : 64);
+      off[k] = (OffT)pl * (OffT)plane + (OffT)(((hz * H + hy) * W + hx) * ldx + (cv - pl * ldx));
+    }
+  }
+  __device__ __forceinline__ void load(const AT* __restrict__ x, int ldx, const TileId& t, int D, int H, int W) {
+    // faces of this brick's halo box that stick out of the volume (+ the never-loaded flag)
+    const int out = (t.z0 == 0 ? 1 : 0) | (t.z0 + TZ == D ? 2 : 0) | (t.y0 == 0 ? 4 : 0) | (t.y0 + TY == H ? 8 : 0) | (t.x0 == 0 ? 16 : 0) | (t.x0 + TX == W ? 32 : 0) | 64;
+    const AT* corner = x + ((((long long)t.img * D + t.z0 - 1) * H + t.y0 - 1) * W + t.x0 - 1) * (long long)ldx;   // may point before the volume: only in-range vectors are read
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
       typename V4<AT>::type q = V4<AT>::zero();
-      if (i < HPOS * VPP) {
-        const int h = i / VPP, v = i - h * VPP;
-        const int hx = h % HX; const int t2 = h / HX; const int hy = t2 % HY; const int hz = t2 / HY;
-        const int z = t.z0 - 1 + hz, y = t.y0 - 1 + hy, xx = t.x0 - 1 + hx;
-        if (v * 4 < cin_load && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) {
-          const size_t pos = (((size_t)t.img * D + z) * H + y) * W + xx;
-          const int cv = v * 4, pl = plane ? cv / ldx : 0;
-          q = V4<AT>::load(x + (size_t)pl * plane + pos * (size_t)ldx + (cv - pl * ldx));
-        }
-      }
+#ifndef SV_ST_PROBE_NOLOAD
+      if ((face[k] & out) == 0) q = V4<AT>::load(corner + off[k]);
+#endif
       r[k] = q;
     }
   }
@@ -92,7 +107,8 @@ struct StencilArgsT {                         // AT = storage element of the act
   int I, D, H, W, ntiles;
 };
 
-template <int G, int NT, typename AT>
+// VEC = every output row window is 4-aligned and has room for the zero pads (the merger's buffers): 8 / 16-byte row stores only
+template <int G, int NT, typename AT, bool VEC>
 __global__ __launch_bounds__(256, G == 1 && NT == 1 ? 4 : 1) void stencil3_fwd_kernel(const StencilArgsT<AT> p) {
   constexpr int C = 16 * G, KTOT = 27 * C, KPAD = (KTOT + 31) / 32 * 32, NSTEP = KPAD / 32;
   __shared__ __attribute__((aligned(16))) char xc[HPOS * C * 2];   // halo brick
@@ -110,7 +126,6 @@ __global__ __launch_bounds__(256, G == 1 && NT == 1 ? 4 : 1) void stencil3_fwd_k
     *reinterpret_cast<bf16x8*>(Ws + n * KPAD + k) = v;
   }
   const int cs4 = (p.cout + 3) & ~3;
-  const bool vec_out = p.out_plane != 0 || (p.ldc & 3) == 0 && (p.col_off & 3) == 0 && p.col_off + cs4 <= p.ldc && (!p.residual || ((p.ldr & 3) == 0 && cs4 <= p.ldr));
   // this lane's output columns: n = nt*16 + lg*4 + j (the accumulators are transposed blocks, see the MFMA loop)
   float bias4[NT][4], st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -119,14 +134,35 @@ __global__ __launch_bounds__(256, G == 1 && NT == 1 ? 4 : 1) void stencil3_fwd_k
     for (int j = 0; j < 4; ++j) { const int n = nt * 16 + lg * 4 + j; bias4[nt][j] = (p.bias && n < p.cout) ? p.bias[n] : 0.f; }
 
   HaloRegs<G, AT> hr;
+  hr.init(p.ldx, p.x_plane, p.cin_load, p.H, p.W, tid);
   int tile = xcd_first_tile();
-  if (tile < p.ntiles) { hr.load(p.x, p.ldx, p.x_plane, p.cin_load, tile_of(tile, p.D, p.H, p.W), p.D, p.H, p.W, tid); hr.store(Xs, tid); }
+  TileId t = tile_of(tile < p.ntiles ? tile : 0, p.D, p.H, p.W);
+  if (tile < p.ntiles) { hr.load(p.x, p.ldx, t, p.D, p.H, p.W); hr.store(Xs, tid); }
   __syncthreads();
   const int yy = lr >> 3, xx = lr & 7;
+  // per lane and MFMA step: the byte offset of the step's (tap, channel chunk) inside the halo image - k = 32 s + 8 lg = tap * C + c
+  int toff[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const int kb = s * 32 + lg * 8;
+    int tap = kb / C; const int c = kb - tap * C;
+    if (tap > 26) tap = 26;                         // padded k: the weights are zero there, any valid address will do
+    const int dz = tap / 9, dy = (tap - dz * 9) / 3, dx = tap - dz * 9 - dy * 3;
+    toff[s] = (((dz * HY + dy) * HX + dx) * C + c) * 2;
+  }
+  const char* xrow = xc + ((wave * HY + yy) * HX + xx) * C * 2;                       // this wave's z-slice, M-tile 0
+  const char* wrow = reinterpret_cast<const char*>(Ws) + (lr * KPAD + lg * 8) * 2;     // weight row lr, this lane's 8 k of step 0
+  // this lane's output columns n0 + j (block nt adds 16 nt), which of them exist, and where its rows start inside a position row
+  const int n0 = lg * 4;
+  bool colreal[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) colreal[nt][j] = nt * 16 + n0 + j < p.cout;
   for (; tile < p.ntiles; tile += gridDim.x) {
-    const TileId t = tile_of(tile, p.D, p.H, p.W);
     const int next = tile + gridDim.x;
-    if (next < p.ntiles) hr.load(p.x, p.ldx, p.x_plane, p.cin_load, tile_of(next, p.D, p.H, p.W), p.D, p.H, p.W, tid);   // in flight during the MFMA loop
+    TileId tn = t;
+    if (next < p.ntiles) { tn = tile_of(next, p.D, p.H, p.W); hr.load(p.x, p.ldx, tn, p.D, p.H, p.W); }   // in flight during the MFMA loop
 
     // this wave: z-slice `wave`; M-tile mt = rows y = 2mt, 2mt+1; fragment row r = lane&15 -> (yy = r>>3, xx = r&7)
     f32x4 acc[4][NT];
@@ -134,66 +170,75 @@ __global__ __launch_bounds__(256, G == 1 && NT == 1 ? 4 : 1) void stencil3_fwd_k
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int abase[4];
+    // A fragment of (M-tile mt, step s): halo row (wave, 2 mt + yy, xx) shifted by the lane's tap of step s, 8 channels from c:
+    // byte address = abase + mt * (2 HX C 2) + toff[s], toff per lane and step from the table set up before the brick loop
+#ifndef SV_ST_PROBE_NOMMA
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) abase[mt] = (wave * HY + 2 * mt + yy) * HX + xx;   // halo index of (z, y, x) shifted by tap (0,0,0)
-#pragma unroll 2
     for (int s = 0; s < NSTEP; ++s) {
-      const int kb = s * 32 + lg * 8;
-      int tap = kb / C; const int c = kb - tap * C;
-      if (tap > 26) tap = 26;                       // padded k: weights are zero there, any valid address will do
-      const int dz = tap / 9, dy = (tap - dz * 9) / 3, dx = tap - dz * 9 - dy * 3;
-      const int off = (dz * HY + dy) * HX + dx;
       bf16x8 b[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(Ws + (nt * 16 + lr) * KPAD + kb);
+      for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(wrow + nt * 16 * KPAD * 2 + s * 64);
+      const char* ap = xrow + toff[s];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xs + (abase[mt] + off) * C + c);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + mt * (2 * HX * C * 2));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt], a, acc[mt][nt], 0, 0, 0);   // B first: transposed block
       }
     }
+#endif
     // With the weight fragment as the MFMA's first operand the accumulator block is transposed: lane (lr, lg) holds voxel
     // row lr = (y = 2mt + (lr >> 3), x = lr & 7) of z-slice `wave`, columns nt*16 + lg*4 .. +3 - four consecutive channels,
     // stored straight from the registers as one vector (no LDS staging of the tile, no extra barriers).
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const size_t pos = (((size_t)t.img * p.D + t.z0 + wave) * p.H + t.y0 + 2 * mt + yy) * p.W + t.x0 + xx;
+    const size_t pos0 = (((size_t)t.img * p.D + t.z0 + wave) * p.H + t.y0 + yy) * p.W + t.x0 + xx;     // M-tile 0; M-tile mt is 2 mt W positions on
+    if constexpr (VEC) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int n0 = nt * 16 + lg * 4;
-        if (n0 >= cs4) continue;
-        float v[4];
+        const int nn = nt * 16 + n0;
+        if (nn >= cs4) continue;
+        AT* orow; const AT* rrow = nullptr;
+        if (p.out_plane) { const int pl = nn / p.ldc; orow = p.out + (size_t)pl * p.out_plane + pos0 * p.ldc + (nn - pl * p.ldc); }
+        else orow = p.out + pos0 * p.ldc + p.col_off + nn;
+        if (p.residual) rrow = p.residual + pos0 * p.ldr + nn;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (n0 + j < p.cout) ? acc[mt][nt][j] + bias4[nt][j] : 0.f;
-        if (NT == 1 && p.stats) {
+        for (int mt = 0; mt < 4; ++mt) {
+          float v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { st1[j] += v[j]; st2[j] += v[j] * v[j]; }
-        }
-        if (vec_out) {
+          for (int j = 0; j < 4; ++j) v[j] = colreal[nt][j] ? acc[mt][nt][j] + bias4[nt][j] : 0.f;
+          if (NT == 1 && p.stats) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { st1[j] += v[j]; st2[j] += v[j] * v[j]; }
+          }
           if (p.residual) {
-            const float4 rv = ld4f(p.residual + pos * p.ldr + n0);
+            const float4 rv = ld4f(rrow + (size_t)mt * 2 * p.W * p.ldr);
             v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
           }
-          if (p.out_plane) {
-            const int pl = n0 / p.ldc;
-            st4f(p.out + (size_t)pl * p.out_plane + pos * p.ldc + (n0 - pl * p.ldc), make_float4(v[0], v[1], v[2], v[3]));
-          } else {
-            st4f(p.out + pos * p.ldc + p.col_off + n0, make_float4(v[0], v[1], v[2], v[3]));
-          }
-        } else {
+#ifdef SV_ST_PROBE_NOSTORE
+          if (v[0] == 1234.5f)
+#endif
+          st4f(orow + (size_t)mt * 2 * p.W * p.ldc, make_float4(v[0], v[1], v[2], v[3]));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const size_t pos = pos0 + (size_t)mt * 2 * p.W;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int nn = nt * 16 + n0;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            if (n0 + j < p.cout) {
-              float r = v[j];
-              if (p.residual) r += ldf(p.residual + pos * p.ldr + n0 + j);
-              stf(p.out + pos * p.ldc + p.col_off + n0 + j, r);
+            if (nn + j < p.cout) {
+              float r = acc[mt][nt][j] + bias4[nt][j];
+              if (NT == 1 && p.stats) { st1[j] += r; st2[j] += r * r; }
+              if (p.residual) r += ldf(p.residual + pos * p.ldr + nn + j);
+              stf(p.out + pos * p.ldc + p.col_off + nn + j, r);
             }
           }
         }
       }
     }
+    t = tn;
     __syncthreads();                                 // every wave is done reading the brick: the next one may land in LDS
     if (next < p.ntiles) hr.store(Xs, tid);
     __syncthreads();
@@ -262,6 +307,7 @@ __global__ __launch_bounds__(256, G == 1 ? 3 : 1) void stencil3_wgrad_kernel(con
   float bsum = 0.f;                                   // bias gradient: column tid&15, voxel group tid>>4
 
   HaloRegs<G, AT> hr;
+  hr.init(p.ldx, p.x_plane, p.cin_load, p.H, p.W, tid);
   typename V4<AT>::type dr[4];                        // dy brick: NVOX voxels x 4 vectors = 4 per thread
   auto load_dy = [&](const TileId& t) {
 #pragma unroll
@@ -283,7 +329,7 @@ __global__ __launch_bounds__(256, G == 1 ? 3 : 1) void stencil3_wgrad_kernel(con
   int tile = xcd_first_tile();
   if (tile < p.ntiles) {
     const TileId t = tile_of(tile, p.D, p.H, p.W);
-    hr.load(p.x, p.ldx, p.x_plane, p.cin_load, t, p.D, p.H, p.W, tid); load_dy(t);
+    hr.load(p.x, p.ldx, t, p.D, p.H, p.W); load_dy(t);
     hr.store(Xs, tid); store_dy();
   }
   __syncthreads();
@@ -291,7 +337,7 @@ __global__ __launch_bounds__(256, G == 1 ? 3 : 1) void stencil3_wgrad_kernel(con
     const int next = tile + gridDim.x;
     if (next < p.ntiles) {
       const TileId t = tile_of(next, p.D, p.H, p.W);
-      hr.load(p.x, p.ldx, p.x_plane, p.cin_load, t, p.D, p.H, p.W, tid); load_dy(t);     // in flight during the MFMA loop
+      hr.load(p.x, p.ldx, t, p.D, p.H, p.W); load_dy(t);     // in flight during the MFMA loop
     }
     if (p.dbias) {
       const int c = tid & 15, vg = tid >> 4;
@@ -500,6 +546,12 @@ static int stencil_check(int I, int D, int H, int W) {
   return SV_OK;
 }
 
+#define SV_STENCIL_LAUNCH(GG, NTT, VV)                                                                                     \
+  do {                                                                                                                    \
+    const int resident = 256 * resident_per_cu((const void*)stencil3_fwd_kernel<GG, NTT, AT, VV>);                        \
+    hipLaunchKernelGGL((stencil3_fwd_kernel<GG, NTT, AT, VV>), dim3(ntiles < resident ? ntiles : resident), dim3(256), 0, s, a); \
+  } while (0)
+
 extern "C" int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups, const void* w_bf16, int ntiles16,
                                const float* bias, void* out, int ldc, int col_off, int cout, const void* residual, int ldr,
                                double* stats, int I, int D, int H, int W, long long x_plane_stride, long long out_plane_stride,
@@ -527,16 +579,13 @@ extern "C" int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups,
   // persistent grid: exactly as many workgroups as stay resident (asked from the runtime per instantiation: registers and
   // LDS decide; a larger grid would queue workgroups behind the resident ones and unbalance the brick loop)
   SV_DISPATCH_ACT(act_dtype,
-    const int per_cu = groups == 1 && ntiles16 == 1 ? resident_per_cu((const void*)stencil3_fwd_kernel<1, 1, AT>)
-                     : groups == 3 ? resident_per_cu((const void*)stencil3_fwd_kernel<3, 1, AT>)
-                                   : resident_per_cu((const void*)stencil3_fwd_kernel<1, 3, AT>);
-    const int resident = 256 * per_cu;
-    const int blocks = ntiles < resident ? ntiles : resident;
+    const int cs4 = (cout + 3) & ~3;
+    const bool vec = out_plane_stride != 0 || ((ldc & 3) == 0 && (col_off & 3) == 0 && col_off + cs4 <= ldc && (!residual || ((ldr & 3) == 0 && cs4 <= ldr)));
     StencilArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, x_plane_stride, out_plane_stride, (const __bf16*)w_bf16, bias, static_cast<AT*>(out), ldc, col_off, cout,
                        static_cast<const AT*>(residual), ldr, stats, I, D, H, W, ntiles};
-    if (groups == 1 && ntiles16 == 1) hipLaunchKernelGGL((stencil3_fwd_kernel<1, 1, AT>), dim3(blocks), dim3(256), 0, s, a);
-    else if (groups == 3) hipLaunchKernelGGL((stencil3_fwd_kernel<3, 1, AT>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((stencil3_fwd_kernel<1, 3, AT>), dim3(blocks), dim3(256), 0, s, a););
+    if (groups == 1 && ntiles16 == 1) { if (vec) SV_STENCIL_LAUNCH(1, 1, true); else SV_STENCIL_LAUNCH(1, 1, false); }
+    else if (groups == 3) { if (vec) SV_STENCIL_LAUNCH(3, 1, true); else SV_STENCIL_LAUNCH(3, 1, false); }
+    else { if (vec) SV_STENCIL_LAUNCH(1, 3, true); else SV_STENCIL_LAUNCH(1, 3, false); });
   return check_launch("sv_stencil3_fwd");
 }
 
