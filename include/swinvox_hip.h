@@ -91,6 +91,10 @@ int sv_conv_gather_is_wide(const void* in, const void* w, void* out, const sv_ge
  * (transposed-conv forward; strided-conv data-grad), decomposed per output parity class            */
 int sv_tconv_gather(const void* in, const void* w_packed, void* out, const sv_geom* g, const sv_epilogue* e,
                     int math, int act_dtype, void* stream);
+/* 1 when sv_conv_wgrad would run this call on the wide weight-gradient kernel (256 x 128 tile of dW, LDS-DMA ring fed by producer waves:
+ * Linear / 1x1 stride-1 layers with bf16 storage, rows % 64 == 0 and >= 16384, >= 128 8-aligned columns on both sides), else 0.
+ * SV_WGRAD_WIDE=0 in the environment disables it. */
+int sv_conv_wgrad_is_wide(const void* anchor, int lda, const void* gathered, const sv_geom* g, int cg_valid, int math, int act_dtype);
 /* weight gradient: dw[ca, cg, tap] += sum_r anchor[r, ca] * gathered[r*s - p + tap, cg]   (fp32 atomics; dw pre-zeroed
  * or holding a running sum).  g->Do.. = anchor grid, g->Di.. = gathered grid, g->Co = anchor channels (row stride lda),
  * g->Ci = gathered channels (stride g->ldi); only cg < cg_valid is written; dw index = (ca*cg_valid + cg)*taps + tap.

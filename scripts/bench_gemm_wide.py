@@ -27,6 +27,7 @@ SHAPES = [  # M, K, N, epilogue
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--wgrad", action="store_true", help="time the weight gradients of the same layers instead (A/B with SV_WGRAD_WIDE=0)")
     ap.add_argument("--cold", action="store_true", help="sweep 1 GB through the caches before every timed launch (the state a layer finds inside a step)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -58,6 +59,12 @@ def main():
         if epi == "stats":
             kw["stats"] = torch.zeros(16, 2 * N, dtype=torch.float64, device=dev)
         fn = lambda: sp.forward(x, M, (1, 1, 1), wp, y, **kw)
+        if a.wgrad:
+            if epi not in ("", "gelu", "stats"):
+                continue
+            dw, db = torch.zeros(N, K, device=dev), (torch.zeros(N, device=dev) if epi == "gelu" else None)
+            dy = torch.randn(M, N, device=dev).bfloat16()
+            fn = lambda: sp.wgrad(dy, x, M, (1, 1, 1), dw, db=db, async_ok=False)
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
@@ -79,7 +86,7 @@ def main():
         tot += us
         flops = 2.0 * M * K * N
         print(f"M={M:8d} K={K:5d} N={N:5d} {epi:6s} {us:9.1f} us  {flops / us / 1e6:7.1f} TF/s", flush=True)
-    print(f"TOTAL {tot:.1f} us  (SV_GEMM_WIDE={os.environ.get('SV_GEMM_WIDE', '1')})")
+    print(f"TOTAL {tot:.1f} us  (SV_GEMM_WIDE={os.environ.get('SV_GEMM_WIDE', '1')} SV_WGRAD_WIDE={os.environ.get('SV_WGRAD_WIDE', '1')})")
 
 
 if __name__ == "__main__":

@@ -1282,6 +1282,159 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, in
 #undef SV_LAUNCH_IG
 }
 
+// ------------------------------------------------------------------------------------------------
+// wide weight-gradient kernel of the dense layers (Linear / 1x1 stride-1, bf16 storage):  dW[co][ci] += sum_r dY[r][co] * X[r][ci].
+// Same machine as gemm_wide_kernel: one workgroup per CU, 8 consumer waves (4 x 2, 64 x 64 each) on a 256 x 128 tile of dW, 4 producer
+// waves that issue the LDS-DMA of 64-row slices of both operands into a ring of three 48 KB slots, one barrier per slice.  The
+// contraction runs over ROWS, so both fragments come out of the [row][column] images through ds_read_b64_tr_b16; the 32-byte column
+// windows of a row are XOR-swizzled by f(row) = (row & 3) | ((row >> 1) & 4) (applied to the DMA source columns), which spreads the
+// 8 rows a 32-lane half reads over all 64 banks.  P = the operand whose columns take the 256-side of the tile (SWAP: X, else dY),
+// Q the other; a workgroup owns one tile and a contiguous range of row slices (workgroups of one row range sit on one XCD: they share
+// the operand rows through its L2) and adds its fp32 tile into dW once, at the end (16 consecutive floats per lane group).
+// Host-side conditions: rows % 64 == 0, 8-aligned columns and row strides, <= 256 tiles (wgrad_wide_ok).
+// ------------------------------------------------------------------------------------------------
+struct WGradWideArgs {
+  const __bf16* P; int ldp; int pcols; const __bf16* Q; int ldq; int qcols;
+  float* dw; int ld_dw;                 // dW[co][ci], row stride = Ci
+  float* dbias;                         // optional: dbias[co] += sum_r dY[r][co] (the workgroups of ONE column of tiles add them up, from the LDS images)
+  int nslices, ntiles, tiles_p, groups; // 64-row slices; tiles = tiles_p x tiles_q; groups = workgroups per tile (grid = ntiles * groups)
+};
+
+template <bool SWAP>
+__global__ __launch_bounds__(GW_NTHR, 3) void wgrad_wide_kernel(const WGradWideArgs p) {
+  __shared__ __attribute__((aligned(1024))) char smem[GW_STAGES * GW_STAGE_BYTES];   // ONE object; slot = P image [64][256] | Q image [64][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bl = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = bl % p.ntiles, grp = bl / p.ntiles;
+  const int p0 = (tile % p.tiles_p) * 256, q0 = (tile / p.tiles_p) * 128;
+  const int sbase = p.nslices / p.groups, srem = p.nslices % p.groups;
+  const int s0 = grp * sbase + (grp < srem ? grp : srem), nsl = sbase + (grp < srem ? 1 : 0);
+  if (nsl <= 0) return;
+
+  if (wave >= GW_NCONS) {
+    // ================= producer wave pw: rows 16 pw .. 16 pw + 15 of every slice (8 P pieces of 2 rows, 4 Q pieces of 4 rows) =================
+    const int pw = wave - GW_NCONS;
+    const __bf16* pp_[8];
+    const __bf16* qp_[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int b = lane >> 5, cd = lane & 31, R = 16 * pw + 2 * i + b;
+      const int fR = (((i & 1) << 1) | b) | (((i >> 2) & 1) << 2);
+      int col = p0 + ((((cd >> 1) ^ fR) << 1) | (cd & 1)) * 8;
+      if (col > p.pcols - 8) col = p.pcols - 8;          // columns past the operand: any valid chunk, the epilogue skips those outputs
+      pp_[i] = p.P + (size_t)(s0 * 64 + R) * p.ldp + col;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = lane >> 4, cd = lane & 15, R = 16 * pw + 4 * i + b;
+      const int fR = b | (((i >> 1) & 1) << 2);
+      int col = q0 + ((((cd >> 1) ^ fR) << 1) | (cd & 1)) * 8;
+      if (col > p.qcols - 8) col = p.qcols - 8;
+      qp_[i] = p.Q + (size_t)(s0 * 64 + R) * p.ldq + col;
+    }
+    auto issue = [&](int kt, int st) {
+      char* base = smem + st * GW_STAGE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((gw_gptr_t)(pp_[i] + (size_t)kt * 64 * p.ldp), (gw_lptr_t)(base + (pw * 8 + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((gw_gptr_t)(qp_[i] + (size_t)kt * 64 * p.ldq), (gw_lptr_t)(base + GW_A_BYTES + (pw * 4 + i) * 1024), 16, 0, 0);
+    };
+    // bias gradient: the dY image of the slice (P, or Q when SWAP) is summed by the producers - each wave its own 16 rows, a lane 4 columns
+    // (8-byte reads through the same window swizzle) - while the consumers contract the slice; only the tiles of the first Q (P) column do it
+    const bool do_bias = p.dbias != nullptr && (SWAP ? tile % p.tiles_p == 0 : tile / p.tiles_p == 0);
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    issue(0, 0);
+    if (nsl > 1) issue(1, 1);
+    int st = 0;
+    for (int kt = 0; kt < nsl; ++kt) {
+      if (kt + 1 < nsl) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (kt + 2 < nsl) issue(kt + 2, st == 0 ? 2 : st - 1);
+      if (do_bias) {
+        const char* sb = smem + st * GW_STAGE_BYTES;
+        if constexpr (!SWAP) {
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            const int R = 16 * pw + rr, fR = (R & 3) | ((R >> 1) & 4);
+            const bf16x4 v = *reinterpret_cast<const bf16x4*>(sb + R * 512 + (((lane >> 2) ^ fR) << 5) + (lane & 3) * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bs[j] += (float)v[j];
+          }
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {   // 32 lanes cover the 128 columns of a row: two rows per read
+            const int R = 16 * pw + 2 * rr + (lane >> 5), fR = (R & 3) | ((R >> 1) & 4);
+            const bf16x4 v = *reinterpret_cast<const bf16x4*>(sb + GW_A_BYTES + R * 256 + ((((lane >> 2) & 7) ^ fR) << 5) + (lane & 3) * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bs[j] += (float)v[j];
+          }
+        }
+      }
+      st = st == 2 ? 0 : st + 1;
+    }
+    if (do_bias) {
+      const int c0 = SWAP ? q0 + (lane & 31) * 4 : p0 + lane * 4, ncol = SWAP ? p.qcols : p.pcols;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < ncol) atomicAdd(p.dbias + c0 + j, bs[j]);
+    }
+    return;
+  }
+
+  // ================= consumer waves: 4 (P) x 2 (Q) grid of 64 x 64 wave tiles =================
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lg = lane >> 4, q = lr >> 2, pq = lr & 3;
+  // fragment (block mt / nt, step ks, half hi) = rows 32 ks + 8 lg + q + 4 hi, 32-byte window (4 wm + mt) ^ f, f = q | (lg & 1) << 2
+  int pofs[4], qofs[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    pofs[t] = (lg * 8 + q) * 512 + pq * 8 + ((wm >> 1) * 8 + (((wm & 1) ^ (lg & 1)) * 4) + (t ^ q)) * 32;
+    qofs[t] = GW_A_BYTES + (lg * 8 + q) * 256 + pq * 8 + (((wn ^ (lg & 1)) * 4) + (t ^ q)) * 32;
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int st = 0;
+  for (int kt = 0; kt < nsl; ++kt) {
+    asm volatile("s_barrier" ::: "memory");               // the slice has landed (the producers waited for it before this barrier)
+    const char* sb = smem + st * GW_STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 pf[4], qf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bf16x4 plo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sb + pofs[t] + ks * 16384));
+        const bf16x4 phi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sb + pofs[t] + ks * 16384 + 2048));
+        pf[t] = __builtin_shufflevector(plo, phi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sb + qofs[t] + ks * 8192));
+        const bf16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sb + qofs[t] + ks * 8192 + 1024));
+        qf[t] = __builtin_shufflevector(qlo, qhi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[nt], pf[mt], acc[mt][nt], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[mt], qf[nt], acc[mt][nt], 0, 0, 0);
+    }
+    st = st == 2 ? 0 : st + 1;
+  }
+  // ---- one fp32 atomic add per element into dW[co][ci]: a lane group's 16 lanes hit 16 consecutive floats
+  //      !SWAP: acc row (4 lg + j) = P column (co), acc column lr = Q column (ci);  SWAP: acc row = Q column (co), acc column = P column (ci)
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pi = p0 + wm * 64 + mt * 16 + (SWAP ? lr : lg * 4 + j), qi = q0 + wn * 64 + nt * 16 + (SWAP ? lg * 4 + j : lr);
+        if (pi < p.pcols && qi < p.qcols) atomicAdd(p.dw + (SWAP ? (size_t)qi * p.ld_dw + pi : (size_t)pi * p.ld_dw + qi), acc[mt][nt][j]);
+      }
+}
+
 typedef Tile<4, 2, 2, 2> WTileDefault;   // 128 anchor channels x 64 (tap, gathered channel), 8 waves
 typedef Tile<1, 4, 1, 2> WTileNarrow;    // 16 x 128 for <=16 anchor channels
 typedef Tile<2, 4, 4, 2> WTileWide;      // 128 x 128, 8 waves
@@ -1356,6 +1509,21 @@ extern "C" size_t sv_conv_wgrad_workspace_floats(const sv_geom* g) {
   return taps == 1 ? 0 : (size_t)g->Co * taps * g->Ci;
 }
 
+// dense layers with bf16 storage take the wide weight-gradient kernel (SV_WGRAD_WIDE=0 in the environment keeps the 128-wide one)
+static bool wgrad_wide_ok(const void* anchor, int lda, const void* gathered, const sv_geom* g, int cg_valid, int math, int act) {
+  static const int wide_on = [] { const char* v = getenv("SV_WGRAD_WIDE"); return v ? atoi(v) : 1; }();
+  const long long Mll = (long long)g->N * g->Do * g->Ho * g->Wo;
+  const bool same_rows = g->kd * g->kh * g->kw == 1 && g->sd == 1 && g->sh == 1 && g->sw == 1 && g->pd == 0 && g->ph == 0 && g->pw == 0 &&
+                         g->Di == g->Do && g->Hi == g->Ho && g->Wi == g->Wo;
+  return wide_on && same_rows && act == SV_BF16 && math == SV_MATH_BF16 && cg_valid == g->Ci && Mll % 64 == 0 && Mll >= 16384 &&
+         g->Co >= 128 && g->Ci >= 128 && ((g->Co | g->Ci | lda | g->ldi) & 7) == 0 && (((uintptr_t)anchor | (uintptr_t)gathered) & 15) == 0 &&
+         (long long)cdiv(g->Co, 128) * cdiv(g->Ci, 128) <= 512;
+}
+/* 1 when sv_conv_wgrad would run this call on the wide kernel (tests) */
+extern "C" int sv_conv_wgrad_is_wide(const void* anchor, int lda, const void* gathered, const sv_geom* g, int cg_valid, int math, int act_dtype) {
+  return g && wgrad_wide_ok(anchor, lda, gathered, g, cg_valid, math, act_dtype) ? 1 : 0;
+}
+
 extern "C" int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, float* dw, const sv_geom* g, int cg_valid,
                              float* workspace, float* dbias, int math, int act_dtype, void* stream) {
   SV_REQUIRE(anchor && gathered && dw && g, "wgrad: null argument");
@@ -1378,6 +1546,27 @@ extern "C" int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, 
   a.dbias = dbias;
   a.out = a.direct ? dw : workspace;
   if (!a.direct) (void)hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)g->Co * Kout, s);
+  {
+    if (wgrad_wide_ok(anchor, lda, gathered, g, cg_valid, math, act)) {
+      // the 256-side of the tile goes to the operand it wastes less on (dY columns = Co, X columns = Ci)
+      const long long w0 = (long long)cdiv(g->Co, 256) * 256 * cdiv(g->Ci, 128) * 128, w1 = (long long)cdiv(g->Ci, 256) * 256 * cdiv(g->Co, 128) * 128;
+      const bool swap = w1 < w0;
+      const int pcols = swap ? g->Ci : g->Co, qcols = swap ? g->Co : g->Ci;
+      const int tiles_p = cdiv(pcols, 256), ntiles = tiles_p * cdiv(qcols, 128);
+      if (ntiles <= 256) {
+        WGradWideArgs wa{};
+        wa.P = static_cast<const __bf16*>(swap ? gathered : anchor); wa.ldp = swap ? g->ldi : lda; wa.pcols = pcols;
+        wa.Q = static_cast<const __bf16*>(swap ? anchor : gathered); wa.ldq = swap ? lda : g->ldi; wa.qcols = qcols;
+        wa.dw = dw; wa.ld_dw = g->Ci; wa.nslices = (int)(Mll / 64); wa.ntiles = ntiles; wa.tiles_p = tiles_p;
+        wa.dbias = dbias;
+        wa.groups = 256 / ntiles;
+        if (wa.groups > wa.nslices) wa.groups = wa.nslices;
+        if (swap) hipLaunchKernelGGL(wgrad_wide_kernel<true>, dim3(ntiles * wa.groups), dim3(GW_NTHR), 0, s, wa);
+        else hipLaunchKernelGGL(wgrad_wide_kernel<false>, dim3(ntiles * wa.groups), dim3(GW_NTHR), 0, s, wa);
+        return check_launch("sv_conv_wgrad");
+      }
+    }
+  }
   const bool narrow = g->Co <= 16;
   const bool wide = !narrow && Kout >= 128;      // 128 x 128 tile: the anchor operand is re-read once per 128 (tap, channel) columns
   const int BMw = narrow ? WTileNarrow::BM : WTileDefault::BM;

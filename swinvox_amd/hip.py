@@ -60,6 +60,7 @@ _PROTOS = {
     "sv_conv_gather": (_I, [_P, _P, _P, C.POINTER(Geom), C.POINTER(Epilogue), _I]),
     "sv_tconv_gather": (_I, [_P, _P, _P, C.POINTER(Geom), C.POINTER(Epilogue), _I]),
     "sv_conv_gather_is_wide": (_I, None, [_P, _P, _P, C.POINTER(Geom), C.POINTER(Epilogue), _I, _I]),
+    "sv_conv_wgrad_is_wide": (_I, None, [_P, _I, _P, C.POINTER(Geom), _I, _I, _I]),
     "sv_conv_wgrad_workspace_floats": (C.c_size_t, None, [C.POINTER(Geom)]),
     "sv_conv_wgrad": (_I, [_P, _I, _P, _P, C.POINTER(Geom), _I, _P, _P, _I]),
     "sv_stencil3_fwd": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _L, _L]),

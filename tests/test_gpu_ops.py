@@ -160,6 +160,31 @@ def test_gemm_wide_kernel(dev, mode):
     assert _is_wide(sp3, xd, M, (1, 1, 1), sp3.pack_fwd(torch.zeros(264, 192, device=dev)), out[:, off:], ldc=ldc) == 0
 
 
+@pytest.mark.parametrize("K,N,bias", [(392, 264, True), (512, 384, False), (384, 512, True)])
+def test_wgrad_wide_kernel(dev, K, N, bias):
+    """csrc/igemm.hip wgrad_wide_kernel (dW = dY^T X of the dense layers in bf16 storage: 256 x 128 tiles, both tile orientations, ragged
+    tiles) against torch on bf16-rounded operands; dW and the bias gradient are accumulated into what is already there."""
+    ops.set_math("bf16"); ops.set_storage("bf16")
+    g = torch.Generator().manual_seed(K + N)
+    M = 64 * 331
+    bf = lambda t: t.bfloat16().float()
+    x, dy = bf(torch.randn(M, K, generator=g)), bf(torch.randn(M, N, generator=g))
+    sp = ConvSpec.linear(K, N)
+    xd, dyd = x.to(dev).bfloat16(), dy.to(dev).bfloat16()
+    gm = sp._geom(M, (1, 1, 1), (1, 1, 1), K, N, K)
+    assert hip.load().sv_conv_wgrad_is_wide(ptr(dyd), N, ptr(xd), C.byref(gm), K, hip.MATH_BF16, hip.BF16) == 1
+    base = torch.randn(N, K, generator=g)
+    dw = base.clone().to(dev)
+    db = torch.ones(N, device=dev) if bias else None
+    sp.wgrad(dyd, xd, M, (1, 1, 1), dw, db=db, async_ok=False)
+    ref = dy.t() @ x
+    assert rel(dw.cpu() - base, ref) < 2e-3
+    if bias:
+        assert rel(db.cpu() - 1.0, dy.sum(0)) < 2e-3
+    gm2 = sp._geom(M - 64 + 8, (1, 1, 1), (1, 1, 1), K, N, K)     # rows not a multiple of the 64-row slice: the 128-wide kernel
+    assert hip.load().sv_conv_wgrad_is_wide(ptr(dyd), N, ptr(xd), C.byref(gm2), K, hip.MATH_BF16, hip.BF16) == 0
+
+
 CONV2D = [  # cin, cout, k, s, p, H
     (64, 64, 3, 1, 1, 14), (256, 256, 3, 2, 1, 14), (64, 128, 1, 2, 0, 14), (3, 64, 7, 2, 3, 32), (3, 96, 4, 4, 0, 32), (512, 256, 3, 1, 1, 7)]
 
