@@ -21,8 +21,8 @@ def family(name: str) -> str:
         for k in ("swin_mlp_fwd_kernel", "swin_mlp_bwd_kernel", "swin_mlp_wgrad_kernel", "swin_mlp_pack_kernel"):
             if k in n:
                 return "fused Swin MLP: " + k
-    if "igemm_kernel" in n or ("wgrad_kernel" in n and "stencil" not in n) or "gemm_dense_kernel" in n:
-        return "contraction engine (igemm_kernel + gemm_dense_kernel + wgrad_kernel)"
+    if "igemm_kernel" in n or ("wgrad_kernel" in n and "stencil" not in n) or "gemm_dense_kernel" in n or "gemm_wide_kernel" in n or "wgrad_wide_kernel" in n:
+        return "contraction engine (igemm_kernel + gemm_dense_kernel + gemm_wide_kernel + wgrad_kernel + wgrad_wide_kernel)"
     if "win_attn_fwd" in n:
         return "window attention forward (win_attn_fwd_*)"
     if "win_attn_bwd" in n:
@@ -33,6 +33,8 @@ def family(name: str) -> str:
         return "LayerNorm passes (ln_* + lnl_*)"
     if "stencil3" in n:
         return "merger stencils (stencil3_*)"
+    if "tconv4s2" in n:
+        return "decoder layer4 halo transposed convolution (tconv4s2_fwd_kernel)"
     return n.replace("void ", "").strip()[-60:]
 
 
