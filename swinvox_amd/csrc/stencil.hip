@@ -60,9 +60,10 @@ struct HaloRegs {
   typename V4<AT>::type r[N];
   OffT off[N];      // element offset from the brick's corner position (z0 - 1, y0 - 1, x0 - 1), channel / plane offset included
   int face[N];      // bit 0 / 1: on the z-low / z-high face of the halo box, 2 / 3: y, 4 / 5: x; bit 6: never loaded
+  int lds[N];       // element offset of the vector in the LDS image [HZ * HY rows][pitch positions][C] (pitch >= HX, see init)
   // plane == 0: position rows of ldx channels; plane != 0: the channels are stored as planes of ldx channels each
   // (memory channel c at x[(c / ldx) * plane + pos * ldx + c % ldx]) - the dense per-layer buffers of the merger's concat
-  __device__ __forceinline__ void init(int ldx, long long plane, int cin_load, int H, int W, int tid) {
+  __device__ __forceinline__ void init(int ldx, long long plane, int cin_load, int H, int W, int tid, int pitch = HX) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const int i = tid + 256 * k;
@@ -72,6 +73,7 @@ struct HaloRegs {
       face[k] = (hz == 0 ? 1 : 0) | (hz == HZ - 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == HY - 1 ? 8 : 0) | (hx == 0 ? 16 : 0) | (hx == HX - 1 ? 32 : 0) |
                 ((i < HPOS * VPP && cv < cin_load) ? 0 : 64);
       off[k] = (OffT)pl * (OffT)plane + (OffT)(((hz * H + hy) * W + hx) * ldx + (cv - pl * ldx));
+      lds[k] = ((hz * HY + hy) * pitch + hx) * C + cv;
     }
   }
   __device__ __forceinline__ void load(const AT* __restrict__ x, int ldx, const TileId& t, int D, int H, int W) {
@@ -91,7 +93,7 @@ struct HaloRegs {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const int i = tid + 256 * k;
-      if (i < HPOS * VPP) *reinterpret_cast<bf16x4*>(Xs + i * 4) = to_bf16x4(r[k]);   // [h][v*4] == linear i*4
+      if (i < HPOS * VPP) *reinterpret_cast<bf16x4*>(Xs + lds[k]) = to_bf16x4(r[k]);
     }
   }
 };
@@ -108,10 +110,15 @@ struct StencilArgsT {                         // AT = storage element of the act
 };
 
 // VEC = every output row window is 4-aligned and has room for the zero pads (the merger's buffers): 8 / 16-byte row stores only
+// Rows of the LDS halo image hold HXP = 16 positions for 16-channel rows (10 are used): the two y-rows of an M-tile are then 512 bytes apart and
+// the four 16-lane groups of an A-fragment ds_read_b128 touch 16 different bank slots each; with the natural pitch of 10 positions (320 B) the
+// rows overlap in half the slots - 2-way conflicts on the reads that bound the MFMA loop (one fragment read per MFMA).  Costs 11.5 KB of LDS:
+// 3 instead of 4 resident workgroups per CU for G = 1.
+template <int G> struct StencilPitch { static constexpr int HXP = G == 1 ? 16 : HX; };
 template <int G, int NT, typename AT, bool VEC>
-__global__ __launch_bounds__(256, G == 1 && NT == 1 ? 4 : 1) void stencil3_fwd_kernel(const StencilArgsT<AT> p) {
-  constexpr int C = 16 * G, KTOT = 27 * C, KPAD = (KTOT + 31) / 32 * 32, NSTEP = KPAD / 32;
-  __shared__ __attribute__((aligned(16))) char xc[HPOS * C * 2];   // halo brick
+__global__ __launch_bounds__(256, G == 1 && NT == 1 ? 3 : 1) void stencil3_fwd_kernel(const StencilArgsT<AT> p) {
+  constexpr int C = 16 * G, KTOT = 27 * C, KPAD = (KTOT + 31) / 32 * 32, NSTEP = KPAD / 32, HXP = StencilPitch<G>::HXP;
+  __shared__ __attribute__((aligned(16))) char xc[HZ * HY * HXP * C * 2];   // halo brick
   __shared__ __attribute__((aligned(16))) __bf16 Ws[NT * 16 * KPAD];
   __shared__ float red[16 * 16 * 2];
   __bf16* Xs = reinterpret_cast<__bf16*>(xc);
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256, G == 1 && NT == 1 ? 4 : 1) void stencil3_fwd_k
     for (int j = 0; j < 4; ++j) { const int n = nt * 16 + lg * 4 + j; bias4[nt][j] = (p.bias && n < p.cout) ? p.bias[n] : 0.f; }
 
   HaloRegs<G, AT> hr;
-  hr.init(p.ldx, p.x_plane, p.cin_load, p.H, p.W, tid);
+  hr.init(p.ldx, p.x_plane, p.cin_load, p.H, p.W, tid, HXP);
   int tile = xcd_first_tile();
   TileId t = tile_of(tile < p.ntiles ? tile : 0, p.D, p.H, p.W);
   if (tile < p.ntiles) { hr.load(p.x, p.ldx, t, p.D, p.H, p.W); hr.store(Xs, tid); }
@@ -148,9 +155,9 @@ __global__ __launch_bounds__(256, G == 1 && NT == 1 ? 4 : 1) void stencil3_fwd_k
     int tap = kb / C; const int c = kb - tap * C;
     if (tap > 26) tap = 26;                         // padded k: the weights are zero there, any valid address will do
     const int dz = tap / 9, dy = (tap - dz * 9) / 3, dx = tap - dz * 9 - dy * 3;
-    toff[s] = (((dz * HY + dy) * HX + dx) * C + c) * 2;
+    toff[s] = (((dz * HY + dy) * HXP + dx) * C + c) * 2;
   }
-  const char* xrow = xc + ((wave * HY + yy) * HX + xx) * C * 2;                       // this wave's z-slice, M-tile 0
+  const char* xrow = xc + ((wave * HY + yy) * HXP + xx) * C * 2;                      // this wave's z-slice, M-tile 0
   const char* wrow = reinterpret_cast<const char*>(Ws) + (lr * KPAD + lg * 8) * 2;     // weight row lr, this lane's 8 k of step 0
   // this lane's output columns n0 + j (block nt adds 16 nt), which of them exist, and where its rows start inside a position row
   const int n0 = lg * 4;
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256, G == 1 && NT == 1 ? 4 : 1) void stencil3_fwd_k
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // A fragment of (M-tile mt, step s): halo row (wave, 2 mt + yy, xx) shifted by the lane's tap of step s, 8 channels from c:
-    // byte address = abase + mt * (2 HX C 2) + toff[s], toff per lane and step from the table set up before the brick loop
+    // byte address = abase + mt * (2 HXP C 2) + toff[s], toff per lane and step from the table set up before the brick loop
 #ifndef SV_ST_PROBE_NOMMA
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(256, G == 1 && NT == 1 ? 4 : 1) void stencil3_fwd_k
       const char* ap = xrow + toff[s];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + mt * (2 * HX * C * 2));
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + mt * (2 * HXP * C * 2));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt], a, acc[mt][nt], 0, 0, 0);   // B first: transposed block
       }
