@@ -224,3 +224,43 @@ def test_graph_replay_equals_the_eager_step(dev, storage):
         assert l1 != l2 and not torch.equal(g1, g2) and bool(torch.isfinite(g2).all())
     finally:
         S.set_math("f32")
+
+
+def test_lr_range_test_follows_the_oracle_loop_and_restores_the_state(dev):
+    """swinvox_amd.lr_finder.lr_range_test (utils/lr_finder.py:84-276 on the HIP train step) against the CPU restatement of that loop on the
+    oracle modules: same learning rates, losses within the fp32 tolerance over 6 steps whose last ones move the weights visibly, the same
+    suggestion rule, initial parameters back in place afterwards."""
+    import oracle as O
+    from oracle import lr_finder as OL
+    from swinvox_amd import lr_finder as L
+    from swinvox_amd.models import Decoder, Encoder, Merger, Refiner
+    S.set_math("f32")
+    ocfg, pcfg = O.default_cfg(), S.default_cfg()
+    onets = [O.Encoder(ocfg), O.Decoder(ocfg), O.Merger(ocfg), O.Refiner(ocfg)]
+    for i, n in enumerate(onets):
+        O.seeded_weights_(n, seed=70 + i)
+        for m in n.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            if isinstance(m, O.model.SwinBlock):
+                m.dp = 0.0
+    pnets = [Encoder(pcfg), Decoder(pcfg), Merger(pcfg), Refiner(pcfg)]
+    for p, o in zip(pnets, onets):
+        p.load_state_dict(o.state_dict())
+        p.to(dev).train()
+        p.stochastic = False
+    before = [{k: v.clone() for k, v in p.state_dict().items()} for p in pnets]
+    g = torch.Generator().manual_seed(3)
+    batches = [((0.5 * torch.randn(1, 2, 3, 224, 224, generator=g)).clamp(-1, 1), (torch.rand(1, 32, 32, 32, generator=g) < 0.1).float()) for _ in range(6)]
+    betas = tuple(pcfg.TRAIN.BETAS)
+    lrs_o, losses_o, sm_o = OL.range_test(onets, ocfg, batches, 1e-5, 3e-3, 6, 0.9, betas=betas)
+    res = L.lr_range_test(pnets, pcfg, [(x.to(dev), y.to(dev)) for x, y in batches], start_lr=1e-5, end_lr=3e-3, num_batches=6, avg_beta=0.9)
+    assert len(res["lrs"]) == 6 and max(abs(a - b) / b for a, b in zip(res["lrs"], lrs_o)) < 1e-12
+    assert abs(losses_o[-1] - losses_o[0]) > 1e-3                                   # the sweep did train (otherwise the comparison says nothing)
+    for a, b in zip(res["losses"], losses_o):
+        assert abs(a - b) < 2e-3 * max(1.0, abs(b))
+    assert max(abs(a - b) for a, b in zip(res["smoothed"], L.smooth(res["losses"], 0.9))) < 1e-12
+    assert res["suggested_lr"] == L.suggest_lr(res["lrs"], res["smoothed"]) and res["diverged_at"] is None
+    for p, sd in zip(pnets, before):                                                # lr_finder.py:270-276: initial state restored
+        now = p.state_dict()
+        assert all(torch.equal(now[k], v) for k, v in sd.items())
