@@ -622,15 +622,20 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR >= 512 ? 4 : 2) void gemm_dense_
 // Epilogue semantics = epilogue_rows (bias / activation(-gradient) / residual / pre-activation copy / statistics).
 // Host-side conditions: K % 64 == 0, K >= 192, 8-aligned rows and columns (gemm_wide_ok).
 // ------------------------------------------------------------------------------------------------
-constexpr int GW_BM = 256, GW_BN = 128, GW_BK = 64, GW_STAGES = 3;
-constexpr int GW_NCONS = 8, GW_NPROD = 4, GW_NTHR = (GW_NCONS + GW_NPROD) * 64;
-constexpr int GW_A_BYTES = GW_BM * GW_BK * 2, GW_STAGE_BYTES = (GW_BM + GW_BN) * GW_BK * 2;   // 32 KB + 16 KB
+constexpr int GW_BN = 128, GW_BK = 64;
 typedef __attribute__((address_space(1))) const void* gw_gptr_t;
 typedef __attribute__((address_space(3))) void* gw_lptr_t;
 
 // GENERAL = the epilogue reads a residual and / or an activation-gradient source; false = bias / activation / pre-activation copy / statistics
-template <bool GENERAL>
-__global__ __launch_bounds__(GW_NTHR, 3) void gemm_wide_kernel(const IGemmArgs p, int ntiles, int* __restrict__ ctr) {
+// WM = consumer wave rows (tile = 64 WM x 128), NPROD producer waves, ring of NST slices.  Built: <4, 4, 3> = 256 x 128, one workgroup per CU.
+// Measured and dropped: <2, 2, 2> = 128 x 128 tiles, TWO workgroups per CU (the idea: a short-K layer's time is its output stream, which only
+// overlaps with a K loop when another workgroup on the CU runs one) - 1.3-1.6 x SLOWER than <4, 4, 3> on every shape of
+// scripts/bench_gemm_wide.py: one slice of lead instead of two and 1.33 x the operand fill per MAC cost more than the overlap returns.
+template <bool GENERAL, int WM, int NPROD, int NST>
+__global__ __launch_bounds__((2 * WM + NPROD) * 64, 3) void gemm_wide_kernel(const IGemmArgs p, int ntiles, int* __restrict__ ctr) {
+  constexpr int GW_NCONS = 2 * WM, GW_BM = 64 * WM, GW_A_BYTES = GW_BM * GW_BK * 2, GW_STAGE_BYTES = (GW_BM + GW_BN) * GW_BK * 2, GW_STAGES = NST;
+  constexpr int PA = GW_BM / 8 / NPROD, PB = GW_BN / 8 / NPROD, LEAD = NST - 1;      // DMA pieces per producer and slice; slices in flight
+  static_assert(PA % 2 == 0 && PB % 2 == 0 && (NST == 2 || NST == 3), "piece parity / ring depth");
   // ONE object (a second one makes hipcc drain the DMA queue): the ring + the two-word mailbox of the tile scheduler + a 1 KB store patch
   // per consumer wave
   __shared__ __attribute__((aligned(1024))) char smem[GW_STAGES * GW_STAGE_BYTES + 64 + GW_NCONS * 1024];
@@ -672,18 +677,18 @@ __global__ __launch_bounds__(GW_NTHR, 3) void gemm_wide_kernel(const IGemmArgs p
     // lane l of piece q = row 8 q + l / 8, slot l % 8 <- chunk (l % 8) ^ (row / 2 mod 8) = (l % 8) ^ (4 (q & 1) | l / 16)
     const int pw = wave - GW_NCONS;
     const int chunk0 = (lane & 7) ^ (lane >> 4);
-    const __bf16* pa[8];
-    const __bf16* pb[4];
+    const __bf16* pa[PA];
+    const __bf16* pb[PB];
     auto set_sources = [&](int r0, int c0) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        int m = r0 + (pw * 8 + i) * 8 + (lane >> 3);
+      for (int i = 0; i < PA; ++i) {
+        int m = r0 + (pw * PA + i) * 8 + (lane >> 3);
         if (m >= Mrows) m = Mrows - 1;                     // rows past the end: any valid row, the epilogue skips them
         pa[i] = X + (size_t)m * g.ldi + (chunk0 ^ ((i & 1) << 2)) * 8;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int n = c0 + (pw * 4 + i) * 8 + (lane >> 3);
+      for (int i = 0; i < PB; ++i) {
+        int n = c0 + (pw * PB + i) * 8 + (lane >> 3);
         if (n >= g.Co) n = g.Co - 1;
         pb[i] = Wt + (size_t)n * p.Ktot + (chunk0 ^ ((i & 1) << 2)) * 8;
       }
@@ -694,24 +699,25 @@ __global__ __launch_bounds__(GW_NTHR, 3) void gemm_wide_kernel(const IGemmArgs p
 #endif
       char* base = smem + st * GW_STAGE_BYTES;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_global_load_lds((gw_gptr_t)(pa[i] + kt * GW_BK), (gw_lptr_t)(base + (pw * 8 + i) * 1024), 16, 0, 0);
+      for (int i = 0; i < PA; ++i)
+        __builtin_amdgcn_global_load_lds((gw_gptr_t)(pa[i] + kt * GW_BK), (gw_lptr_t)(base + (pw * PA + i) * 1024), 16, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((gw_gptr_t)(pb[i] + kt * GW_BK), (gw_lptr_t)(base + GW_A_BYTES + (pw * 4 + i) * 1024), 16, 0, 0);
+      for (int i = 0; i < PB; ++i)
+        __builtin_amdgcn_global_load_lds((gw_gptr_t)(pb[i] + kt * GW_BK), (gw_lptr_t)(base + GW_A_BYTES + (pw * PB + i) * 1024), 16, 0, 0);
     };
+    static_assert(NST == 2 || PA + PB == 12, "the counted wait below is written for 12 pieces per slice");
     set_sources(row0, col0);
     issue(0, 0);
-    issue(1, 1);                                          // nk >= 3
+    if (LEAD == 2) issue(1, 1);                           // nk >= 3
     int st = 0;
     bool have = true;
     while (have) {
       bool more = true;                                   // known from the second slice on (nk >= 3: the last slice is a later one)
       unsigned drawn = 0;
       for (int kt = 0; kt < nk; ++kt) {
-        // this wave's pieces of the slice have landed (the 12 of the next slice may stay in flight); behind the barrier every
-        // producer's have, and every consumer is done reading the previous slice, whose ring slot the slice after next overwrites
-        if (kt + 1 < nk || more) asm volatile("s_waitcnt vmcnt(12)" : "+v"(drawn) :: "memory");
+        // this wave's pieces of the slice have landed (ring of 3: the 12 of the next slice may stay in flight); behind the barrier every
+        // producer's have, and every consumer is done reading the previous slice, whose ring slot the next issue overwrites
+        if (NST == 3 && (kt + 1 < nk || more)) asm volatile("s_waitcnt vmcnt(12)" : "+v"(drawn) :: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn) :: "memory");
         if (kt == 1 && pw == 0 && lane == 0) {            // the draw of slice 0 is older than the 12 pieces waited past: it has returned
           const int v = (int)drawn;
@@ -725,20 +731,20 @@ __global__ __launch_bounds__(GW_NTHR, 3) void gemm_wide_kernel(const IGemmArgs p
         }
         if (kt == 0 && pw == 0 && lane == 0)              // draw the next tile: an atomic hipcc does not count (it would drain the DMA queue for it)
           asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(ctr + xcd), "v"(1u) : "memory");
-        const int st2 = st == 0 ? 2 : st - 1;
-        if (kt + 2 < nk) issue(kt + 2, st2);
+        const int st2 = st == 0 ? NST - 1 : st - 1;       // = (st + LEAD) mod NST: the slot consumed a slice ago
+        if (kt + LEAD < nk) issue(kt + LEAD, st2);
         else if (more) {
-          if (kt + 2 == nk) set_sources(row0n, col0n);   // the current tile's last slice was issued an iteration ago
-          issue(kt + 2 - nk, st2);
+          if (kt + LEAD == nk) set_sources(row0n, col0n); // the current tile's last slice was issued an iteration ago
+          issue(kt + LEAD - nk, st2);
         }
-        st = st == 2 ? 0 : st + 1;
+        st = st == NST - 1 ? 0 : st + 1;
       }
       have = more; ++it;
     }
     return;
   }
 
-  // ================= consumer waves: 4 x 2 grid of 64 x 64 wave tiles =================
+  // ================= consumer waves: WM x 2 grid of 64 x 64 wave tiles =================
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lg = lane >> 4;
   // fragment addresses: row lr of a 16-row block, k chunk 4 ks + lg -> slot (4 ks + lg) ^ (lr / 2)
   int aoff[2], boff[2];
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(GW_NTHR, 3) void gemm_wide_kernel(const IGemmArgs p
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ks][nt], a[ks][mt], acc[mt][nt], 0, 0, 0);
 #endif
-      st = st == 2 ? 0 : st + 1;
+      st = st == NST - 1 ? 0 : st + 1;
     }
 
     // ---- epilogue on the registers: lane (lr, lg) of block (mt, nt) = row mt * 16 + lr, columns nt * 16 + lg * 4 .. + 3.
@@ -1205,17 +1211,15 @@ static bool gemm_wide_ok(const IGemmArgs& a, long long M) {
   const Epi& e = a.e;
   const int K = a.g.Ci, Co = a.g.Co;
   if (!enabled || K % GW_BK || K < 3 * GW_BK || Co < 128 || a.Ktot % 8) return false;
-  // where it wins (scripts/bench_gemm_wide.py, M = 25k .. 400k): deep K; short K only with many output columns; BatchNorm producers
-  // (two double atomics per column and 64 rows) only when the K loop is long enough to carry them
-  if (enabled == 1 && !(K >= 384 || (K >= 192 && Co >= 384))) return false;
+  // where it wins (scripts/bench_gemm_wide.py, M = 25k .. 400k): everything from K = 192 on, except the BatchNorm producers (two double
+  // atomics per column and 64 rows), which need a K loop long enough to carry them
   if (enabled == 1 && e.stats && K < 1024) return false;
   if (((e.ldc | e.col_off | Co) & 7) || (e.residual && (e.ldr & 7))) return false;
   // the general epilogue variant keeps no statistics registers and one set of prefetched rows (residual OR activation-gradient source)
   if ((e.stats && (e.residual || e.act_grad_src)) || (e.residual && e.act_grad_src)) return false;
   if (((uintptr_t)a.y | (uintptr_t)e.residual | (uintptr_t)e.pre_act | (uintptr_t)e.act_grad_src | (uintptr_t)a.w) & 15) return false;
-  return (long long)cdiv(M, GW_BM) * cdiv(Co, GW_BN) >= 256;
+  return (long long)cdiv(M, 256) * cdiv(Co, GW_BN) >= 256;
 }
-
 template <bool TCONV>
 static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, int act, hipStream_t s) {
   const int Co = a.g.Co;
@@ -1252,10 +1256,11 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, in
   } while (0)
   if constexpr (!TCONV) {
     if (dense && gemm_wide_ok(a, M) && gemm_wide_counters_ready()) {
-      const int ntiles = cdiv(M, GW_BM) * cdiv(Co, GW_BN);
       int* ctr = gemm_wide_counters();
-      if (a.e.residual || a.e.act_grad_src) hipLaunchKernelGGL(gemm_wide_kernel<true>, dim3(256), dim3(GW_NTHR), 0, s, a, ntiles, ctr);
-      else hipLaunchKernelGGL(gemm_wide_kernel<false>, dim3(256), dim3(GW_NTHR), 0, s, a, ntiles, ctr);
+      const bool general = a.e.residual || a.e.act_grad_src;
+      const int ntiles = cdiv(M, 256) * cdiv(Co, GW_BN);
+      if (general) hipLaunchKernelGGL((gemm_wide_kernel<true, 4, 4, 3>), dim3(256), dim3(768), 0, s, a, ntiles, ctr);
+      else hipLaunchKernelGGL((gemm_wide_kernel<false, 4, 4, 3>), dim3(256), dim3(768), 0, s, a, ntiles, ctr);
       return;
     }
     if (dense && Co > 16) {
@@ -1300,6 +1305,8 @@ struct WGradWideArgs {
   int nslices, ntiles, tiles_p, groups; // 64-row slices; tiles = tiles_p x tiles_q; groups = workgroups per tile (grid = ntiles * groups)
 };
 
+constexpr int GW_NCONS = 8, GW_NPROD = 4, GW_NTHR = (GW_NCONS + GW_NPROD) * 64, GW_STAGES = 3;                 // geometry of the weight-gradient kernel
+constexpr int GW_A_BYTES = 256 * GW_BK * 2, GW_STAGE_BYTES = (256 + GW_BN) * GW_BK * 2;                          // 32 KB + 16 KB
 template <bool SWAP>
 __global__ __launch_bounds__(GW_NTHR, 3) void wgrad_wide_kernel(const WGradWideArgs p) {
   __shared__ __attribute__((aligned(1024))) char smem[GW_STAGES * GW_STAGE_BYTES];   // ONE object; slot = P image [64][256] | Q image [64][128]

@@ -151,13 +151,14 @@ def test_gemm_wide_kernel(dev, mode):
     if mode == "stats":
         st, o = stats.sum(0).cpu(), got.cpu().double()
         assert rel(st[:N], o.sum(0)) < 1e-4 and rel(st[N:], (o * o).sum(0)) < 1e-4
-    # K not a multiple of the 64-deep slice, short K with few columns and small problems stay on the 128-wide kernels
+    # K not a multiple of the 64-deep slice, K < 192 and small problems stay on the 128-wide kernels
     sp2 = ConvSpec.linear(K + 32, N)
     x2 = torch.zeros(M, K + 32, dtype=torch.bfloat16, device=dev)
     assert _is_wide(sp2, x2, M, (1, 1, 1), sp2.pack_fwd(torch.zeros(N, K + 32, device=dev)), out[:, off:], ldc=ldc) == 0
     assert _is_wide(sp, xd[:4096], 4096, (1, 1, 1), wp, out[:4096, off:], ldc=ldc) == 0
-    sp3 = ConvSpec.linear(192, 264)
-    assert _is_wide(sp3, xd, M, (1, 1, 1), sp3.pack_fwd(torch.zeros(264, 192, device=dev)), out[:, off:], ldc=ldc) == 0
+    sp3 = ConvSpec.linear(128, 264)                              # fewer than three 64-deep slices
+    x3 = torch.zeros(M, 128, dtype=torch.bfloat16, device=dev)
+    assert _is_wide(sp3, x3, M, (1, 1, 1), sp3.pack_fwd(torch.zeros(264, 128, device=dev)), out[:, off:], ldc=ldc) == 0
 
 
 @pytest.mark.parametrize("K,N,bias", [(392, 264, True), (512, 384, False), (384, 512, True)])
