@@ -471,8 +471,12 @@ def traced_call(name, flops, nbytes, *args, tag=""):
 
 def fused_mlp_enabled(C: int) -> bool:
     """The fused Swin MLP kernels (csrc/swin_mlp.hip) serve bf16 MFMA + bf16 storage and the channel counts they are built for."""
+    import os
+    # C = 192 (Swin-T stage 1) is built too, but since the wide dense kernels (csrc/igemm.hip) serve K = 192 the unfused chain is the faster
+    # one there: 123.0 -> 121.7 ms per step at B = 64.  SV_FUSED_MLP_MAX_C overrides the limit for measurements.
+    lim = int(os.environ.get("SV_FUSED_MLP_MAX_C", "128"))
     return (_STATE.get("fused_mlp", True) and _STATE["math"] == hip.MATH_BF16 and _STATE["store"] == torch.bfloat16
-            and hip.load().sv_swin_mlp_supported(C) == 1)
+            and C <= lim and hip.load().sv_swin_mlp_supported(C) == 1)
 
 
 def set_attention_fp8(on: bool) -> None:
