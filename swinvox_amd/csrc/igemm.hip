@@ -623,6 +623,14 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR >= 512 ? 4 : 2) void gemm_dense_
 // Host-side conditions: K % 64 == 0, K >= 192, 8-aligned rows and columns (gemm_wide_ok).
 // ------------------------------------------------------------------------------------------------
 constexpr int GW_BN = 128, GW_BK = 64;
+template <int CTRL> __device__ __forceinline__ float gw_dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row; valid in lane 15 of the row (row_shr 1, 2, 4, 8 with zero fill)
+__device__ __forceinline__ float row16_total(float v) {
+  v = gw_dpp_add<0x111>(v); v = gw_dpp_add<0x112>(v); v = gw_dpp_add<0x114>(v); v = gw_dpp_add<0x118>(v);
+  return v;
+}
 typedef __attribute__((address_space(1))) const void* gw_gptr_t;
 typedef __attribute__((address_space(3))) void* gw_lptr_t;
 
@@ -892,11 +900,10 @@ __global__ __launch_bounds__((2 * WM + NPROD) * 64, 3) void gemm_wide_kernel(con
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float a1 = s1[nt][j], a2 = s2[nt][j];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+            // the 16 lanes of a row: four DPP row shifts leave the total in lane 15 (a __shfl_xor goes through the LDS crossbar)
+            const float a1 = row16_total(s1[nt][j]), a2 = row16_total(s2[nt][j]);
             const int n = nbase + nt * 16 + j;
-            if (lr == 0 && n < g.Co) { atomicAdd(stp + n, (double)a1); atomicAdd(stp + g.Co + n, (double)a2); }
+            if (lr == 15 && n < g.Co) { atomicAdd(stp + n, (double)a1); atomicAdd(stp + g.Co + n, (double)a2); }
           }
       }
     }
