@@ -41,13 +41,20 @@ struct TokMap {  // window -> token rows of the un-shifted [I,H,W] map
   }
 };
 
+// all-reduce over the 16 lanes of a DPP row, every lane gets the result: quad_perm xor 1, xor 2, row_half_mirror (i <-> 7 - i: the two quads
+// of a half), row_mirror (i <-> 15 - i: the two halves).  Four VALU DPP moves instead of four ds_bpermute round trips through the LDS crossbar.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float group16_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
-  v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+  v = fmaxf(v, dpp_mov<0xB1>(v));     // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_mov<0x4E>(v));     // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_mov<0x141>(v));    // row_half_mirror
+  v = fmaxf(v, dpp_mov<0x140>(v));    // row_mirror
   return v;
 }
 __device__ __forceinline__ float group16_sum(float v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
   return v;
 }
 
@@ -877,7 +884,11 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
     for (int it = 0; it < 2; ++it) {
       const int r = (tid >> 3) + 32 * it, ch = (tid & 7) * 4;
       rq[it] = V4<AT>::zero(); rk[it] = rq[it]; rv[it] = rq[it]; rd[it] = rq[it];
+#ifdef SV_AT_PROBE_NOFETCH
+      if (r < 0) {
+#else
       if (r < WT) {
+#endif
         const size_t row = tn.row(r);
         const AT* src = p.qkv + row * ld + colq + ch;
         rq[it] = V4<AT>::load(src); rk[it] = V4<AT>::load(src + p.C); rv[it] = V4<AT>::load(src + 2 * p.C);
@@ -915,7 +926,9 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
         dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, d, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       }
     }
+#ifndef SV_AT_PROBE_NOSOFTMAX
     bias_mask_softmax_strip(s, bias, tm, lane, p.shift > 0 && (tm.wy == p.H / 7 - 1 || tm.wx == nWx - 1), wave);
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float r = 0.f;
@@ -935,7 +948,9 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int o = (wave * 16 + lg * 4 + j) * LDP_H + nt * 16 + lr;
+#ifndef SV_AT_PROBE_NOPS
         Ps[o] = (__bf16)s[nt][j]; Ss[o] = (__bf16)dp[nt][j];
+#endif
       }
     __syncthreads();
     // ---- rows of this wave: keys 16w.. for dV = P^T dO and dK = dS^T (scale Q); queries 16w.. for dQ = scale dS K
