@@ -100,14 +100,19 @@ int check_launch(const char* what);
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// all-reduce over the 16 lanes of a DPP row with VALU moves (quad_perm xor 1, xor 2, row_half_mirror, row_mirror); the two steps across rows
+// go through __shfl_xor (LDS crossbar).  Every lane gets the result.
+template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += dpp_move<0xB1>(v); v += dpp_move<0x4E>(v); v += dpp_move<0x141>(v); v += dpp_move<0x140>(v);
+  v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, dpp_move<0xB1>(v)); v = fmaxf(v, dpp_move<0x4E>(v)); v = fmaxf(v, dpp_move<0x141>(v)); v = fmaxf(v, dpp_move<0x140>(v));
+  v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 

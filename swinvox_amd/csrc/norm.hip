@@ -51,10 +51,15 @@ __device__ __forceinline__ void ldp(const float* p, float* v, int n) {   // n = 
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
   if (n == 8) { const float4 b = *reinterpret_cast<const float4*>(p + 4); v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
 }
+template <int CTRL> __device__ __forceinline__ float ln_dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 template <int LPR>
-__device__ __forceinline__ float group_sum(float v) {   // sum over the LPR lanes that share a row
+__device__ __forceinline__ float group_sum(float v) {   // sum over the LPR (16 / 32 / 64) lanes that share a row, every lane gets it
+  // inside a 16-lane DPP row: quad_perm xor 1, xor 2, row_half_mirror, row_mirror (VALU moves, no LDS crossbar round trips)
+  v += ln_dpp_mov<0xB1>(v); v += ln_dpp_mov<0x4E>(v); v += ln_dpp_mov<0x141>(v); v += ln_dpp_mov<0x140>(v);
 #pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 16; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
@@ -130,25 +135,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
     if (ch < nchunk) ldp(gamma + ch * VEC, gm[i], VEC);
   }
   const long long r0 = (long long)blockIdx.x * rows_per_block;
-  for (int rr = wave * RPW + gr; rr < rows_per_block; rr += RPI) {
+  // The rows of the NEXT iteration are fetched before this iteration's stores: vmcnt retires in issue order, so loads issued behind a store
+  // can only be waited for by draining the store - one store round trip per iteration otherwise.
+  float xv[NV][VEC], dv[NV][VEC], ov[NV][VEC], mean = 0.f, rstd = 0.f;
+  bool rok = false;
+  auto fetch = [&](int rr, float (&xo)[NV][VEC], float (&d_)[NV][VEC], float (&old)[NV][VEC], float& mn, float& rs, bool& ok) {
     const long long row = r0 + rr;
-    const bool rok = row < rows;                 // whole row groups stay in the loop: the group reductions need every lane
-    const float mean = rok ? mean_in[row] : 0.f, rstd = rok ? rstd_in[row] : 0.f;
+    ok = rr < rows_per_block && row < rows;
+    mn = ok ? mean_in[row] : 0.f; rs = ok ? rstd_in[row] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int ch = gl + LPR * i;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { xo[i][j] = 0.f; d_[i][j] = 0.f; old[i][j] = 0.f; }
+      if (ok && ch < nchunk) {
+        LnIO<VEC, AT>::load(x + ln_src_off<MERGE>(row, ch * VEC, C, mm), xo[i]);
+        LnIO<VEC, AT>::load(dy + (size_t)row * C + ch * VEC, d_[i]);
+        if (accumulate_dx) LnIO<VEC, AT>::load(dx + ln_src_off<MERGE>(row, ch * VEC, C, mm), old[i]);
+      }
+    }
+  };
+  fetch(wave * RPW + gr, xv, dv, ov, mean, rstd, rok);
+  for (int rr = wave * RPW + gr; rr < rows_per_block; rr += RPI) {   // whole row groups stay in the loop: the group reductions need every lane
+    const long long row = r0 + rr;
+    float xn[NV][VEC], dn[NV][VEC], on[NV][VEC], mean_n, rstd_n;
+    bool rok_n;
+    fetch(rr + RPI, xn, dn, on, mean_n, rstd_n, rok_n);
     float xh[NV][VEC], g[NV][VEC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int ch = gl + LPR * i;
       if (rok && ch < nchunk) {
-        float xv[VEC], d[VEC];
-        LnIO<VEC, AT>::load(x + ln_src_off<MERGE>(row, ch * VEC, C, mm), xv);
-        LnIO<VEC, AT>::load(dy + (size_t)row * C + ch * VEC, d);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          xh[i][j] = (xv[j] - mean) * rstd;
-          g[i][j] = d[j] * gm[i][j];
+          xh[i][j] = (xv[i][j] - mean) * rstd;
+          g[i][j] = dv[i][j] * gm[i][j];
           s1 += g[i][j]; s2 += g[i][j] * xh[i][j];
-          dg[i][j] += d[j] * xh[i][j]; db[i][j] += d[j];
+          dg[i][j] += dv[i][j] * xh[i][j]; db[i][j] += dv[i][j];
         }
       }
     }
@@ -159,17 +183,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
       if (rok && ch < nchunk) {
         float o[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o[j] = rstd * (g[i][j] - m1 - xh[i][j] * m2);
-        AT* dst = dx + ln_src_off<MERGE>(row, ch * VEC, C, mm);
-        if (accumulate_dx) {
-          float old[VEC];
-          LnIO<VEC, AT>::load(dst, old);
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) o[j] += old[j];
-        }
-        LnIO<VEC, AT>::store(dst, o);
+        for (int j = 0; j < VEC; ++j) o[j] = rstd * (g[i][j] - m1 - xh[i][j] * m2) + ov[i][j];
+        LnIO<VEC, AT>::store(dx + ln_src_off<MERGE>(row, ch * VEC, C, mm), o);
       }
     }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { xv[i][j] = xn[i][j]; dv[i][j] = dn[i][j]; ov[i][j] = on[i][j]; }
+    mean = mean_n; rstd = rstd_n; rok = rok_n;
   }
   __syncthreads();
 #pragma unroll

@@ -253,8 +253,8 @@ __global__ __launch_bounds__(256, G == 1 && NT == 1 ? 3 : 1) void stencil3_fwd_k
   if (NT == 1 && p.stats) {                          // per-channel sum / sum of squares of the stored values (without residual)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { st1[j] += __shfl_xor(st1[j], o, 64); st2[j] += __shfl_xor(st2[j], o, 64); }
+      { st1[j] += dpp_move<0xB1>(st1[j]); st1[j] += dpp_move<0x4E>(st1[j]); st1[j] += dpp_move<0x141>(st1[j]); st1[j] += dpp_move<0x140>(st1[j]);
+        st2[j] += dpp_move<0xB1>(st2[j]); st2[j] += dpp_move<0x4E>(st2[j]); st2[j] += dpp_move<0x141>(st2[j]); st2[j] += dpp_move<0x140>(st2[j]); }
     }
     if (lr == 0) {
 #pragma unroll
