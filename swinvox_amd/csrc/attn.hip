@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void cva_attn_bwd_kernel(const CvaArgsT<AT> p)
 // bias + mask + softmax over the keys for ONE 16-row strip (query rows mt*16 + lg*4 + j, keys nt*16 + lr).
 // The relative-position bias of this lane's 16 (query, key) slots is the same for every window of a head: it is gathered
 // once per workgroup into registers (strip_bias); the shifted-window mask only exists in the last window row / column.
-__device__ __forceinline__ void strip_bias(float (&bias)[4][4], const float* bt, int lane, int mt) {
+__device__ __forceinline__ void strip_bias(float (&bias)[4][4], const float* bt, int lane, int mt, float mul = 1.f) {
   const int lr = lane & 15, lg = lane >> 4;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
@@ -575,10 +575,14 @@ __device__ __forceinline__ void strip_bias(float (&bias)[4][4], const float* bt,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int q = mt * 16 + lg * 4 + j, qy = q / 7, qx = q - qy * 7;
-      bias[nt][j] = key >= WT ? -1.0e30f : (q < WT ? bt[(qy - ky + 6) * 13 + (qx - kx + 6)] : 0.f);   // key padding: excluded
+      bias[nt][j] = key >= WT ? -1.0e30f : (q < WT ? mul * bt[(qy - ky + 6) * 13 + (qx - kx + 6)] : 0.f);   // key padding: excluded
     }
   }
 }
+// LOG2: scores and bias arrive multiplied by log2(e) (the forward folds the factor into the scale of Q and into the bias strip), so the
+// exponential is one v_exp_f32 without the multiply __expf carries
+constexpr float ATTN_LOG2E = 1.4426950408889634f;
+template <bool LOG2 = false>
 __device__ __forceinline__ void bias_mask_softmax_strip(f32x4 (&s)[4], const float (&bias)[4][4], const TokMap& tm, int lane, bool masked, int mt) {
   const int lr = lane & 15, lg = lane >> 4;
   if (masked) {   // a window touching the rolled seam: tokens of different regions must not attend to each other
@@ -591,7 +595,7 @@ __device__ __forceinline__ void bias_mask_softmax_strip(f32x4 (&s)[4], const flo
       const int qreg = q < WT ? tm.region(q) : 0;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
-        if (q < WT && nt * 16 + lr < WT && qreg != kreg[nt]) s[nt][j] += -100.0f;
+        if (q < WT && nt * 16 + lr < WT && qreg != kreg[nt]) s[nt][j] += LOG2 ? -100.0f * ATTN_LOG2E : -100.0f;
     }
   }
 #pragma unroll
@@ -606,8 +610,8 @@ __device__ __forceinline__ void bias_mask_softmax_strip(f32x4 (&s)[4], const flo
     mx = group16_max(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { const float e = __expf(s[nt][j] - mx); s[nt][j] = e; sum += e; }
-    const float inv = 1.f / group16_sum(sum);
+    for (int nt = 0; nt < 4; ++nt) { const float e = LOG2 ? __builtin_amdgcn_exp2f(s[nt][j] - mx) : __expf(s[nt][j] - mx); s[nt][j] = e; sum += e; }
+    const float inv = __builtin_amdgcn_rcpf(group16_sum(sum));   // 1 ulp: the quotient is rounded to bf16 right after (an IEEE division is ~10 instructions)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) s[nt][j] *= inv;
   }
@@ -680,7 +684,8 @@ __global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<
   for (int i = tid; i < HD * LDP_H; i += 256) Vt[i] = (__bf16)0.f;      // key columns >= 49 stay zero
   __syncthreads();
   float bias[4][4];
-  strip_bias(bias, bt, lane, wave);
+  strip_bias(bias, bt, lane, wave, ATTN_LOG2E);
+  const float qscale = p.scale * ATTN_LOG2E;      // scores come out of the MFMA in log2 units
   const long long task0 = (long long)chunk * p.tasks_per_wave;
   for (int tt = 0; tt < p.tasks_per_wave; ++tt) {
     const long long task = task0 + tt;
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<
         q4 = ld4f(src); k4 = ld4f(src + p.C); v4 = ld4f(src + 2 * p.C);
       }
       bf16x4 qb, kb;
-      qb[0] = (__bf16)(q4.x * p.scale); qb[1] = (__bf16)(q4.y * p.scale); qb[2] = (__bf16)(q4.z * p.scale); qb[3] = (__bf16)(q4.w * p.scale);
+      qb[0] = (__bf16)(q4.x * qscale); qb[1] = (__bf16)(q4.y * qscale); qb[2] = (__bf16)(q4.z * qscale); qb[3] = (__bf16)(q4.w * qscale);
       kb[0] = (__bf16)k4.x; kb[1] = (__bf16)k4.y; kb[2] = (__bf16)k4.z; kb[3] = (__bf16)k4.w;
       *reinterpret_cast<bf16x4*>(Qs + r * LDQ_H + ch) = qb;
       *reinterpret_cast<bf16x4*>(Ks + r * LDQ_H + ch) = kb;
@@ -715,7 +720,7 @@ __global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<
         s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       }
     }
-    bias_mask_softmax_strip(s, bias, tm, lane, p.shift > 0 && (tm.wy == p.H / 7 - 1 || tm.wx == nWx - 1), wave);
+    bias_mask_softmax_strip<true>(s, bias, tm, lane, p.shift > 0 && (tm.wy == p.H / 7 - 1 || tm.wx == nWx - 1), wave);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
