@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const AT* __restrict__ x, c
       for (int j = 0; j < VEC; ++j) s += v[i][j];
     }
   }
-  const float mean = group_sum<LPR>(s) / C;
+  const float invC = 1.f / C;                                   // one division per thread, not two per row
+  const float mean = group_sum<LPR>(s) * invC;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const AT* __restrict__ x, c
       for (int j = 0; j < VEC; ++j) { const float a = v[i][j] - mean; q += a * a; }
     }
   }
-  const float rstd = rsqrtf(group_sum<LPR>(q) / C + eps);
+  const float rstd = rsqrtf(group_sum<LPR>(q) * invC + eps);
   if (rok && gl == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
     if (ch < nchunk) ldp(gamma + ch * VEC, gm[i], VEC);
   }
   const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const float invC = 1.f / C;
   // The rows of the NEXT iteration are fetched before this iteration's stores: vmcnt retires in issue order, so loads issued behind a store
   // can only be waited for by draining the store - one store round trip per iteration otherwise.
   float xv[NV][VEC], dv[NV][VEC], ov[NV][VEC], mean = 0.f, rstd = 0.f;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const AT* __restrict__ dy, 
         }
       }
     }
-    const float m1 = group_sum<LPR>(s1) / C, m2 = group_sum<LPR>(s2) / C;
+    const float m1 = group_sum<LPR>(s1) * invC, m2 = group_sum<LPR>(s2) * invC;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int ch = gl + LPR * i;
