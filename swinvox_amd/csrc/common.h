@@ -137,24 +137,29 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7) on the fast exponential: ~14 instructions against ~50 of erff.
-// Used by the bf16-MFMA kernels (their operands carry 3 decimal digits); exact-fp32 mode keeps erff / expf.
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(1.f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float r = 1.f - poly * __expf(-ax * ax);
-  return copysignf(r, x);
+// GELU of the bf16-MFMA paths: Phi(x) as the logistic of an odd quintic fitted to the normal CDF, sigma(x (c0 + c1 x^2 + c2 x^4)), x^2 clamped at 64:
+// |GELU - GELU_erf| <= 2.9e-5, derivative <= 1.1e-4 (1/30 of the bf16 rounding unit of the stored value) - the form the fused MLP kernels use
+// (swin_mlp.hip).  5 VALU + v_exp_f32 + v_rcp_f32 against ~30 for the A&S erf above with its IEEE division; the epilogues of fc1 (GELU) and of
+// fc2's data gradient (GELU') carry 64 activations per lane and tile.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float x2 = fminf(x * x, 64.f);
+  const float p = fmaf(x2, fmaf(x2, 9.975397e-04f, -1.0665937e-01f), -2.3012706e+00f);    // -log2(e) * (c0 + c1 x^2 + c2 x^4)
+  return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * p));
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  const float x2 = fminf(x * x, 64.f);
+  const float p = fmaf(x2, fmaf(x2, 9.975397e-04f, -1.0665937e-01f), -2.3012706e+00f);
+  const float s = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * p));
+  const float qd = fmaf(x2, fmaf(x2, -3.45720919e-03f, 2.21791923e-01f), 1.59511919f);     // d/dx [x (c0 + c1 x^2 + c2 x^4)]
+  return s * fmaf(x * (1.f - s), qd, 1.f);
 }
 template <bool FAST> __device__ __forceinline__ float gelu_t(float x) {
-  if constexpr (FAST) return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752440f));
+  if constexpr (FAST) return gelu_fast(x);
   else return gelu_erf(x);
 }
 template <bool FAST> __device__ __forceinline__ float gelu_grad_t(float x) {
-  if constexpr (FAST) {
-    const float cdf = 0.5f * (1.f + erf_fast(x * 0.70710678118654752440f));
-    return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
-  } else return gelu_erf_grad(x);
+  if constexpr (FAST) return gelu_grad_fast(x);
+  else return gelu_erf_grad(x);
 }
 template <bool FAST> __device__ __forceinline__ float apply_act_t(float v, int act, float slope) {
   switch (act) {
