@@ -41,10 +41,11 @@ __device__ __forceinline__ int xcd_first_tile() {
 }
 
 struct TileId { int img, z0, y0, x0; };
+template <int TZV = TZ>
 __device__ __forceinline__ TileId tile_of(int t, int D, int H, int W) {
-  const int tz = D / TZ, ty = H / TY, tx = W / TX;
+  const int tz = D / TZV, ty = H / TY, tx = W / TX;
   TileId r;
-  r.x0 = (t % tx) * TX; t /= tx; r.y0 = (t % ty) * TY; t /= ty; r.z0 = (t % tz) * TZ; r.img = t / tz;
+  r.x0 = (t % tx) * TX; t /= tx; r.y0 = (t % ty) * TY; t /= ty; r.z0 = (t % tz) * TZV; r.img = t / tz;
   return r;
 }
 
@@ -53,9 +54,10 @@ __device__ __forceinline__ TileId tile_of(int t, int D, int H, int W) {
 // corner and which faces of the halo box it lies on.  A brick then costs, per vector, one AND + compare (does a face it lies on stick
 // out of the volume?), one 64-bit add and the load - the div / mod chains and 64-bit multiplies that used to run per vector and brick
 // were the bulk of the kernel's instructions (the 9 -> 9 forward: 3,000 instructions around 8 MFMAs).
-template <int G, typename AT>
+template <int G, typename AT, int TZV = TZ, int NTHR = 256>   // TZV = brick depth (z-slices = waves of the forward kernel), NTHR = threads sharing the brick
 struct HaloRegs {
-  static constexpr int C = 16 * G, VPP = C / 4, N = (HPOS * VPP + 255) / 256;
+  static constexpr int HZV = TZV + 2, HPOSV = HZV * HY * HX;
+  static constexpr int C = 16 * G, VPP = C / 4, N = (HPOSV * VPP + NTHR - 1) / NTHR;
   typedef typename std::conditional<G == 1, int, long long>::type OffT;   // planes (G > 1) can lie > 2^31 elements apart
   typename V4<AT>::type r[N];
   OffT off[N];      // element offset from the brick's corner position (z0 - 1, y0 - 1, x0 - 1), channel / plane offset included
@@ -66,19 +68,19 @@ struct HaloRegs {
   __device__ __forceinline__ void init(int ldx, long long plane, int cin_load, int H, int W, int tid, int pitch = HX) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const int i = tid + 256 * k;
+      const int i = tid + NTHR * k;
       const int h = i / VPP, v = i - h * VPP;
       const int hx = h % HX; const int t2 = h / HX; const int hy = t2 % HY; const int hz = t2 / HY;
       const int cv = v * 4, pl = plane ? cv / ldx : 0;
-      face[k] = (hz == 0 ? 1 : 0) | (hz == HZ - 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == HY - 1 ? 8 : 0) | (hx == 0 ? 16 : 0) | (hx == HX - 1 ? 32 : 0) |
-                ((i < HPOS * VPP && cv < cin_load) ? 0 : 64);
+      face[k] = (hz == 0 ? 1 : 0) | (hz == HZV - 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == HY - 1 ? 8 : 0) | (hx == 0 ? 16 : 0) | (hx == HX - 1 ? 32 : 0) |
+                ((i < HPOSV * VPP && cv < cin_load) ? 0 : 64);
       off[k] = (OffT)pl * (OffT)plane + (OffT)(((hz * H + hy) * W + hx) * ldx + (cv - pl * ldx));
       lds[k] = ((hz * HY + hy) * pitch + hx) * C + cv;
     }
   }
   __device__ __forceinline__ void load(const AT* __restrict__ x, int ldx, const TileId& t, int D, int H, int W) {
     // faces of this brick's halo box that stick out of the volume (+ the never-loaded flag)
-    const int out = (t.z0 == 0 ? 1 : 0) | (t.z0 + TZ == D ? 2 : 0) | (t.y0 == 0 ? 4 : 0) | (t.y0 + TY == H ? 8 : 0) | (t.x0 == 0 ? 16 : 0) | (t.x0 + TX == W ? 32 : 0) | 64;
+    const int out = (t.z0 == 0 ? 1 : 0) | (t.z0 + TZV == D ? 2 : 0) | (t.y0 == 0 ? 4 : 0) | (t.y0 + TY == H ? 8 : 0) | (t.x0 == 0 ? 16 : 0) | (t.x0 + TX == W ? 32 : 0) | 64;
     const AT* corner = x + ((((long long)t.img * D + t.z0 - 1) * H + t.y0 - 1) * W + t.x0 - 1) * (long long)ldx;   // may point before the volume: only in-range vectors are read
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -92,8 +94,8 @@ struct HaloRegs {
   __device__ __forceinline__ void store(__bf16* Xs, int tid) const {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const int i = tid + 256 * k;
-      if (i < HPOS * VPP) *reinterpret_cast<bf16x4*>(Xs + lds[k]) = to_bf16x4(r[k]);
+      const int i = tid + NTHR * k;
+      if (i < HPOSV * VPP) *reinterpret_cast<bf16x4*>(Xs + lds[k]) = to_bf16x4(r[k]);
     }
   }
 };
@@ -115,10 +117,15 @@ struct StencilArgsT {                         // AT = storage element of the act
 // rows overlap in half the slots - 2-way conflicts on the reads that bound the MFMA loop (one fragment read per MFMA).  Costs 11.5 KB of LDS:
 // 3 instead of 4 resident workgroups per CU for G = 1.
 template <int G> struct StencilPitch { static constexpr int HXP = G == 1 ? 16 : HX; };
+// Brick depth of the forward kernel = its wave count (a wave owns one z-slice of 64 voxels).  16-channel rows: 4 x 8 x 8 bricks, 4 waves, 3 (NT = 1)
+// workgroups per CU.  48-channel rows (G = 3, the 36 -> 9 layer): the 58 KB halo + 42 KB of weights allow ONE workgroup per CU, so it takes
+// 8 x 8 x 8 bricks on 8 waves (96 KB halo): two waves per SIMD instead of one and 1.95 instead of 2.34 halo positions loaded per voxel.
+template <int G> struct StencilBrick { static constexpr int TZV = G == 3 ? 8 : 4, NTHR = TZV * 64; };
 template <int G, int NT, typename AT, bool VEC>
-__global__ __launch_bounds__(256, G == 1 && NT == 1 ? 3 : 1) void stencil3_fwd_kernel(const StencilArgsT<AT> p) {
+__global__ __launch_bounds__(StencilBrick<G>::NTHR, G == 1 && NT == 1 ? 3 : (G == 3 ? 2 : 1)) void stencil3_fwd_kernel(const StencilArgsT<AT> p) {
   constexpr int C = 16 * G, KTOT = 27 * C, KPAD = (KTOT + 31) / 32 * 32, NSTEP = KPAD / 32, HXP = StencilPitch<G>::HXP;
-  __shared__ __attribute__((aligned(16))) char xc[HZ * HY * HXP * C * 2];   // halo brick
+  constexpr int TZV = StencilBrick<G>::TZV, NTHR = StencilBrick<G>::NTHR, NW = NTHR / 64;
+  __shared__ __attribute__((aligned(16))) char xc[(TZV + 2) * HY * HXP * C * 2];   // halo brick
   __shared__ __attribute__((aligned(16))) __bf16 Ws[NT * 16 * KPAD];
   __shared__ float red[16 * 16 * 2];
   __bf16* Xs = reinterpret_cast<__bf16*>(xc);
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(256, G == 1 && NT == 1 ? 3 : 1) void stencil3_fwd_k
   const int lr = lane & 15, lg = lane >> 4;
 
   // weights -> LDS once per workgroup (16-byte vectors; rows padded with zeros to a multiple of 32 k)
-  for (int i = tid; i < NT * 16 * KPAD / 8; i += 256) {
+  for (int i = tid; i < NT * 16 * KPAD / 8; i += NTHR) {
     const int n = (i * 8) / KPAD, k = (i * 8) - n * KPAD;
     bf16x8 v = VecN<__bf16, 8>::zero();
     if (k < KTOT) v = *reinterpret_cast<const bf16x8*>(p.w + (size_t)n * KTOT + k);
@@ -140,10 +147,10 @@ __global__ __launch_bounds__(256, G == 1 && NT == 1 ? 3 : 1) void stencil3_fwd_k
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int n = nt * 16 + lg * 4 + j; bias4[nt][j] = (p.bias && n < p.cout) ? p.bias[n] : 0.f; }
 
-  HaloRegs<G, AT> hr;
+  HaloRegs<G, AT, TZV, NTHR> hr;
   hr.init(p.ldx, p.x_plane, p.cin_load, p.H, p.W, tid, HXP);
   int tile = xcd_first_tile();
-  TileId t = tile_of(tile < p.ntiles ? tile : 0, p.D, p.H, p.W);
+  TileId t = tile_of<TZV>(tile < p.ntiles ? tile : 0, p.D, p.H, p.W);
   if (tile < p.ntiles) { hr.load(p.x, p.ldx, t, p.D, p.H, p.W); hr.store(Xs, tid); }
   __syncthreads();
   const int yy = lr >> 3, xx = lr & 7;
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256, G == 1 && NT == 1 ? 3 : 1) void stencil3_fwd_k
   for (; tile < p.ntiles; tile += gridDim.x) {
     const int next = tile + gridDim.x;
     TileId tn = t;
-    if (next < p.ntiles) { tn = tile_of(next, p.D, p.H, p.W); hr.load(p.x, p.ldx, tn, p.D, p.H, p.W); }   // in flight during the MFMA loop
+    if (next < p.ntiles) { tn = tile_of<TZV>(next, p.D, p.H, p.W); hr.load(p.x, p.ldx, tn, p.D, p.H, p.W); }   // in flight during the MFMA loop
 
     // this wave: z-slice `wave`; M-tile mt = rows y = 2mt, 2mt+1; fragment row r = lane&15 -> (yy = r>>3, xx = r&7)
     f32x4 acc[4][NT];
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(256, G == 1 && NT == 1 ? 3 : 1) void stencil3_fwd_k
     if (tid < 16 && tid < p.cout) {
       float a = 0.f, b = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { a += red[(w * 16 + tid) * 2]; b += red[(w * 16 + tid) * 2 + 1]; }
+      for (int w = 0; w < NW; ++w) { a += red[(w * 16 + tid) * 2]; b += red[(w * 16 + tid) * 2 + 1]; }
       double* st = p.stats + (size_t)(blockIdx.x % SV_BN_SLOTS) * 2 * p.cout;
       atomicAdd(st + tid, (double)a);
       atomicAdd(st + p.cout + tid, (double)b);
@@ -296,30 +303,33 @@ __global__ __launch_bounds__(256) void stencil_wgrad_fold_kernel(const float* __
   dw[i] += a;
 }
 
+// Brick depth / wave count as in the forward kernel (StencilBrick): 48-channel rows take 8 x 8 x 8 bricks on 8 waves (one workgroup per CU either
+// way: two waves per SIMD instead of one); the NW waves split the 27 taps.
 template <int G, typename AT>
-__global__ __launch_bounds__(256, G == 1 ? 3 : 1) void stencil3_wgrad_kernel(const StencilWArgsT<AT> p) {
-  constexpr int C = 16 * G;
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[HPOS * C];
-  __shared__ __attribute__((aligned(16))) __bf16 Ds[NVOX * 16];
-  __shared__ float bred[16 * 16];
+__global__ __launch_bounds__(StencilBrick<G>::NTHR, G == 1 ? 3 : 2) void stencil3_wgrad_kernel(const StencilWArgsT<AT> p) {
+  constexpr int C = 16 * G, TZV = StencilBrick<G>::TZV, NTHR = StencilBrick<G>::NTHR, NW = NTHR / 64, NTAPW = (27 + NW - 1) / NW;
+  constexpr int HPOSV = (TZV + 2) * HY * HX, NVOXV = TZV * TY * TX;
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[HPOSV * C];
+  __shared__ __attribute__((aligned(16))) __bf16 Ds[NVOXV * 16];
+  __shared__ float bred[NTHR / 16 * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4, q = lr >> 2, pp = lr & 3;
-  // taps of this wave: t = wave + 4*i, i < NTAP
-  const int ntap = (27 - wave + 3) / 4;
-  f32x4 acc[7][G];
+  // taps of this wave: t = wave + NW * i, i < ntap
+  const int ntap = (27 - wave + NW - 1) / NW;
+  f32x4 acc[NTAPW][G];
 #pragma unroll
-  for (int i = 0; i < 7; ++i)
+  for (int i = 0; i < NTAPW; ++i)
 #pragma unroll
     for (int gg = 0; gg < G; ++gg) acc[i][gg] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;                                   // bias gradient: column tid&15, voxel group tid>>4
 
-  HaloRegs<G, AT> hr;
+  HaloRegs<G, AT, TZV, NTHR> hr;
   hr.init(p.ldx, p.x_plane, p.cin_load, p.H, p.W, tid);
-  typename V4<AT>::type dr[4];                        // dy brick: NVOX voxels x 4 vectors = 4 per thread
+  typename V4<AT>::type dr[4];                        // dy brick: NVOXV voxels x 4 vectors = 4 per thread
   auto load_dy = [&](const TileId& t) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int i = tid + 256 * k;
+      const int i = tid + NTHR * k;
       const int v = i >> 2, c4 = i & 3;
       const int xx = v % TX; const int t2 = v / TX; const int yy = t2 % TY; const int zz = t2 / TY;
       typename V4<AT>::type qv = V4<AT>::zero();
@@ -330,12 +340,12 @@ __global__ __launch_bounds__(256, G == 1 ? 3 : 1) void stencil3_wgrad_kernel(con
   };
   auto store_dy = [&]() {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<bf16x4*>(Ds + (tid + 256 * k) * 4) = to_bf16x4(dr[k]);   // [voxel][16] == linear i*4
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<bf16x4*>(Ds + (tid + NTHR * k) * 4) = to_bf16x4(dr[k]);   // [voxel][16] == linear i*4
   };
 
   int tile = xcd_first_tile();
   if (tile < p.ntiles) {
-    const TileId t = tile_of(tile, p.D, p.H, p.W);
+    const TileId t = tile_of<TZV>(tile, p.D, p.H, p.W);
     hr.load(p.x, p.ldx, t, p.D, p.H, p.W); load_dy(t);
     hr.store(Xs, tid); store_dy();
   }
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(256, G == 1 ? 3 : 1) void stencil3_wgrad_kernel(con
   for (; tile < p.ntiles; tile += gridDim.x) {
     const int next = tile + gridDim.x;
     if (next < p.ntiles) {
-      const TileId t = tile_of(next, p.D, p.H, p.W);
+      const TileId t = tile_of<TZV>(next, p.D, p.H, p.W);
       hr.load(p.x, p.ldx, t, p.D, p.H, p.W); load_dy(t);     // in flight during the MFMA loop
     }
     if (p.dbias) {
@@ -351,18 +361,18 @@ __global__ __launch_bounds__(256, G == 1 ? 3 : 1) void stencil3_wgrad_kernel(con
 #pragma unroll
       for (int k = 0; k < 16; ++k) bsum += (float)Ds[(vg * 16 + k) * 16 + c];
     }
-    // 8 chunks of 32 voxels: chunk = (z, half); k = 8*g + j  <->  (y = 4*half + g, x = j)
+    // 2 TZV chunks of 32 voxels: chunk = (z, half); k = 8*g + j  <->  (y = 4*half + g, x = j)
 #pragma unroll 1
-    for (int ch = 0; ch < 8; ++ch) {
+    for (int ch = 0; ch < 2 * TZV; ++ch) {
       const int z = ch >> 1, yb = (ch & 1) * 4 + lg;
       const __bf16* asrc = Ds + (((z * TY + yb) * TX) + q) * 16 + pp * 4;       // rows = 4 consecutive x positions
       const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(asrc));
       const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(asrc + 4 * 16));
       const bf16x8 a = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
+      for (int i = 0; i < NTAPW; ++i) {
         if (i < ntap) {
-          const int tap = wave + 4 * i;
+          const int tap = wave + NW * i;
           const int dz = tap / 9, dy = (tap - dz * 9) / 3, dx = tap - dz * 9 - dy * 3;
           const int hb = ((z + dz) * HY + yb + dy) * HX + dx + q;
 #pragma unroll
@@ -386,16 +396,16 @@ __global__ __launch_bounds__(256, G == 1 ? 3 : 1) void stencil3_wgrad_kernel(con
     if (tid < 16 && tid < p.cout) {
       float a = 0.f;
 #pragma unroll
-      for (int g2 = 0; g2 < 16; ++g2) a += bred[g2 * 16 + tid];
+      for (int g2 = 0; g2 < NTHR / 16; ++g2) a += bred[g2 * 16 + tid];
       atomicAdd(p.dbias + tid, a);
     }
   }
   // C element: row = lg*4 + j -> co, col = lr -> memory channel 16*gg + lr
   float* dst = p.ws ? p.ws + (size_t)(blockIdx.x % WG_SLOTS) * p.cout * p.cin * 27 : p.dw;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
+  for (int i = 0; i < NTAPW; ++i) {
     if (i < ntap) {
-      const int tap = wave + 4 * i;
+      const int tap = wave + NW * i;
 #pragma unroll
       for (int gg = 0; gg < G; ++gg) {
         const int cm = gg * 16 + lr;
@@ -536,14 +546,14 @@ __global__ __launch_bounds__(256, 2) void tconv4s2_fwd_kernel(const TConv4Args p
 using namespace sv;
 
 // resident 256-thread workgroups per CU of a kernel (cached per instantiation; 1 if the runtime cannot tell)
-static int resident_per_cu(const void* kernel) {
+static int resident_per_cu(const void* kernel, int threads = 256) {
   static std::mutex mu;
   static std::map<const void*, int> cache;
   std::lock_guard<std::mutex> lk(mu);
   auto it = cache.find(kernel);
   if (it != cache.end()) return it->second;
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
   cache[kernel] = n;
   return n;
 }
@@ -555,8 +565,11 @@ static int stencil_check(int I, int D, int H, int W) {
 
 #define SV_STENCIL_LAUNCH(GG, NTT, VV)                                                                                     \
   do {                                                                                                                    \
-    const int resident = 256 * resident_per_cu((const void*)stencil3_fwd_kernel<GG, NTT, AT, VV>);                        \
-    hipLaunchKernelGGL((stencil3_fwd_kernel<GG, NTT, AT, VV>), dim3(ntiles < resident ? ntiles : resident), dim3(256), 0, s, a); \
+    constexpr int nthr = StencilBrick<GG>::NTHR;                                                                          \
+    const int nt_ = I * (D / StencilBrick<GG>::TZV) * (H / TY) * (W / TX);                                                \
+    a.ntiles = nt_;                                                                                                       \
+    const int resident = 256 * resident_per_cu((const void*)stencil3_fwd_kernel<GG, NTT, AT, VV>, nthr);                  \
+    hipLaunchKernelGGL((stencil3_fwd_kernel<GG, NTT, AT, VV>), dim3(nt_ < resident ? nt_ : resident), dim3(nthr), 0, s, a); \
   } while (0)
 
 extern "C" int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups, const void* w_bf16, int ntiles16,
@@ -569,6 +582,7 @@ extern "C" int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups,
              "stencil3_fwd: planar output needs col_off == 0, no residual and whole planes of ldc (multiple of 4) columns");
   SV_REQUIRE_ACT(act_dtype);
   if (int rc = stencil_check(I, D, H, W)) return rc;
+  SV_REQUIRE(groups != 3 || D % 8 == 0, "stencil3_fwd: the 48-channel kernel walks 8x8x8 bricks (D = %d)", D);
   SV_REQUIRE(cin_load % 4 == 0 && cin_load <= 16 * groups && ldx % 4 == 0 && (x_plane_stride ? cin_load % ldx == 0 : ldx >= cin_load),
              "stencil3_fwd: bad input channels (cin_load=%d ldx=%d groups=%d)", cin_load, ldx, groups);
   SV_REQUIRE(cout > 0 && cout <= 16 * ntiles16 && (out_plane_stride || ldc >= col_off + cout), "stencil3_fwd: bad output window");
@@ -610,16 +624,18 @@ extern "C" int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int group
   SV_REQUIRE(cout > 0 && cout <= 16 && cin > 0 && c_stride > 0 && c_valid > 0, "stencil3_wgrad: bad channel counts");
   SV_REQUIRE((((uintptr_t)x | (uintptr_t)dy) & (act_dtype == SV_BF16 ? 7 : 15)) == 0, "stencil3_wgrad: operands must be aligned to 4 elements");
   SV_REQUIRE(groups == 1 || groups == 3, "stencil3_wgrad: unsupported groups=%d", groups);
-  const int ntiles = I * (D / TZ) * (H / TY) * (W / TX);
+  SV_REQUIRE(groups != 3 || D % 8 == 0, "stencil3_wgrad: the 48-channel kernel walks 8x8x8 bricks (D = %d)", D);
+  const int ntiles = I * (D / (groups == 3 ? StencilBrick<3>::TZV : StencilBrick<1>::TZV)) * (H / TY) * (W / TX);
   hipStream_t s = (hipStream_t)stream;
   SV_DISPATCH_ACT(act_dtype,
-    const int per_cu = groups == 1 ? resident_per_cu((const void*)stencil3_wgrad_kernel<1, AT>) : resident_per_cu((const void*)stencil3_wgrad_kernel<3, AT>);
+    const int per_cu = groups == 1 ? resident_per_cu((const void*)stencil3_wgrad_kernel<1, AT>, StencilBrick<1>::NTHR)
+                                   : resident_per_cu((const void*)stencil3_wgrad_kernel<3, AT>, StencilBrick<3>::NTHR);
     const int resident = 256 * per_cu;
     const int blocks = ntiles < resident ? ntiles : resident;
     StencilWArgsT<AT> a{static_cast<const AT*>(x), ldx, cin_load, x_plane_stride, static_cast<const AT*>(dy), lddy, cout_load, dw, workspace, dbias, cout, cin, c_stride, c_valid,
                         I, D, H, W, ntiles};
-    if (groups == 1) hipLaunchKernelGGL((stencil3_wgrad_kernel<1, AT>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((stencil3_wgrad_kernel<3, AT>), dim3(blocks), dim3(256), 0, s, a););
+    if (groups == 1) hipLaunchKernelGGL((stencil3_wgrad_kernel<1, AT>), dim3(blocks), dim3(StencilBrick<1>::NTHR), 0, s, a);
+    else hipLaunchKernelGGL((stencil3_wgrad_kernel<3, AT>), dim3(blocks), dim3(StencilBrick<3>::NTHR), 0, s, a););
   if (workspace) hipLaunchKernelGGL(stencil_wgrad_fold_kernel, dim3(cdiv(cout * cin * 27, 256)), dim3(256), 0, s, workspace, dw, cout * cin * 27);
   return check_launch("sv_stencil3_wgrad");
 }
