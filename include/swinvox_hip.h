@@ -111,7 +111,7 @@ int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, float* dw, 
  * (= residual[pos*ldr + n] + value when residual != NULL); optional per-channel statistics as in sv_epilogue.stats
  * (ntiles16 == 1 only).  When ldc, col_off (and ldr) are multiples of 4 and the row has room, the columns
  * cout .. roundup4(cout)-1 are treated as PADDING of the row and written too (zero, + residual): 8/16-byte row stores.
- * Persistent kernel: one workgroup walks many 4x8x8 bricks, prefetching the next brick while it contracts the current one.
+ * Persistent kernel: one workgroup walks many 8x8x8 bricks (D % 8 == 0, H % 8 == 0, W % 8 == 0), prefetching the next brick while it contracts the current one.
  * Planar channel storage (the dense per-layer buffers that replace the reference's torch.cat, merger.py:84): with
  * x_plane_stride != 0 memory channel c of the input lives at x[(c / ldx) * x_plane_stride + pos*ldx + c % ldx]; with
  * out_plane_stride != 0 column n goes to out[(n / ldc) * out_plane_stride + pos*ldc + n % ldc] (col_off 0, no residual).

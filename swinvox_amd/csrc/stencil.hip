@@ -1,7 +1,7 @@
 // LDS-halo MFMA stencils for the <=16-channel 3x3x3 convolutions of the 32^3 tail (merger, models/merger.py:20-54).
 //
 // The generic implicit-GEMM engine gathers every (voxel, tap) operand row from L2 (27 x 48 B per voxel) and pads the
-// 9 output channels to a 64-wide tile; here a workgroup owns 4x8x8 bricks of voxels, stages a brick + halo ONCE in LDS
+// 9 output channels to a 64-wide tile; here a workgroup owns 8x8x8 (weight gradient of 16-channel rows: 4x8x8) bricks of voxels, stages a brick + halo ONCE in LDS
 // as bf16 [position][16 channels] (32 B rows) and feeds the MFMA straight from it:
 //   forward / data-gradient:  out[vox, n] = sum_{tap, c} x[vox + tap, c] * w[n, tap, c]
 //       A fragment (voxel rows, 8 consecutive channels of one tap) = ONE 16-byte LDS read; weights [16n][27][16G] in LDS.
@@ -117,14 +117,17 @@ struct StencilArgsT {                         // AT = storage element of the act
 // rows overlap in half the slots - 2-way conflicts on the reads that bound the MFMA loop (one fragment read per MFMA).  Costs 11.5 KB of LDS:
 // 3 instead of 4 resident workgroups per CU for G = 1.
 template <int G> struct StencilPitch { static constexpr int HXP = G == 1 ? 16 : HX; };
-// Brick depth of the forward kernel = its wave count (a wave owns one z-slice of 64 voxels).  16-channel rows: 4 x 8 x 8 bricks, 4 waves, 3 (NT = 1)
-// workgroups per CU.  48-channel rows (G = 3, the 36 -> 9 layer): the 58 KB halo + 42 KB of weights allow ONE workgroup per CU, so it takes
-// 8 x 8 x 8 bricks on 8 waves (96 KB halo): two waves per SIMD instead of one and 1.95 instead of 2.34 halo positions loaded per voxel.
-template <int G> struct StencilBrick { static constexpr int TZV = G == 3 ? 8 : 4, NTHR = TZV * 64; };
+// Brick depth = wave count of the workgroup (in the forward kernel a wave owns one z-slice of 64 voxels).  48-channel rows (G = 3, the 36 -> 9
+// layer): with 4 x 8 x 8 bricks the 58 KB halo + 42 KB of weights allowed ONE 4-wave workgroup per CU; 8 x 8 x 8 bricks on 8 waves (96 KB halo)
+// give two waves per SIMD and 1.95 instead of 2.34 halo positions loaded per voxel (forward 1.62 -> 1.15 ms, weight gradient 1.59 -> 1.19 ms).
+template <int G> struct StencilBrick { static constexpr int TZV = G == 3 ? 8 : 4, NTHR = TZV * 64; };   // weight-gradient kernel
+// The forward kernels take 8 x 8 x 8 bricks for 16-channel rows too (two 8-wave workgroups per CU, 65 KB of LDS each): 1.95 instead of 2.34 halo
+// positions per voxel; measured against 4 x 8 x 8 on 4 waves x 3 workgroups: 9 -> 9 forward 434 -> 399 us, data gradient 497 -> 471, 9 -> 36 841 -> 765.
+template <int G> struct StencilBrickF { static constexpr int TZV = 8, NTHR = TZV * 64; };
 template <int G, int NT, typename AT, bool VEC>
-__global__ __launch_bounds__(StencilBrick<G>::NTHR, G == 1 && NT == 1 ? 3 : (G == 3 ? 2 : 1)) void stencil3_fwd_kernel(const StencilArgsT<AT> p) {
+__global__ __launch_bounds__(StencilBrickF<G>::NTHR, 2) void stencil3_fwd_kernel(const StencilArgsT<AT> p) {
   constexpr int C = 16 * G, KTOT = 27 * C, KPAD = (KTOT + 31) / 32 * 32, NSTEP = KPAD / 32, HXP = StencilPitch<G>::HXP;
-  constexpr int TZV = StencilBrick<G>::TZV, NTHR = StencilBrick<G>::NTHR, NW = NTHR / 64;
+  constexpr int TZV = StencilBrickF<G>::TZV, NTHR = StencilBrickF<G>::NTHR, NW = NTHR / 64;
   __shared__ __attribute__((aligned(16))) char xc[(TZV + 2) * HY * HXP * C * 2];   // halo brick
   __shared__ __attribute__((aligned(16))) __bf16 Ws[NT * 16 * KPAD];
   __shared__ float red[16 * 16 * 2];
@@ -565,8 +568,8 @@ static int stencil_check(int I, int D, int H, int W) {
 
 #define SV_STENCIL_LAUNCH(GG, NTT, VV)                                                                                     \
   do {                                                                                                                    \
-    constexpr int nthr = StencilBrick<GG>::NTHR;                                                                          \
-    const int nt_ = I * (D / StencilBrick<GG>::TZV) * (H / TY) * (W / TX);                                                \
+    constexpr int nthr = StencilBrickF<GG>::NTHR;                                                                         \
+    const int nt_ = I * (D / StencilBrickF<GG>::TZV) * (H / TY) * (W / TX);                                               \
     a.ntiles = nt_;                                                                                                       \
     const int resident = 256 * resident_per_cu((const void*)stencil3_fwd_kernel<GG, NTT, AT, VV>, nthr);                  \
     hipLaunchKernelGGL((stencil3_fwd_kernel<GG, NTT, AT, VV>), dim3(nt_ < resident ? nt_ : resident), dim3(nthr), 0, s, a); \
@@ -582,7 +585,7 @@ extern "C" int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups,
              "stencil3_fwd: planar output needs col_off == 0, no residual and whole planes of ldc (multiple of 4) columns");
   SV_REQUIRE_ACT(act_dtype);
   if (int rc = stencil_check(I, D, H, W)) return rc;
-  SV_REQUIRE(groups != 3 || D % 8 == 0, "stencil3_fwd: the 48-channel kernel walks 8x8x8 bricks (D = %d)", D);
+  SV_REQUIRE(D % 8 == 0, "stencil3_fwd: the forward kernels walk 8x8x8 bricks (D = %d)", D);
   SV_REQUIRE(cin_load % 4 == 0 && cin_load <= 16 * groups && ldx % 4 == 0 && (x_plane_stride ? cin_load % ldx == 0 : ldx >= cin_load),
              "stencil3_fwd: bad input channels (cin_load=%d ldx=%d groups=%d)", cin_load, ldx, groups);
   SV_REQUIRE(cout > 0 && cout <= 16 * ntiles16 && (out_plane_stride || ldc >= col_off + cout), "stencil3_fwd: bad output window");
