@@ -1,7 +1,7 @@
 // LDS-halo MFMA stencils for the <=16-channel 3x3x3 convolutions of the 32^3 tail (merger, models/merger.py:20-54).
 //
 // The generic implicit-GEMM engine gathers every (voxel, tap) operand row from L2 (27 x 48 B per voxel) and pads the
-// 9 output channels to a 64-wide tile; here a workgroup owns 8x8x8 (weight gradient of 16-channel rows: 4x8x8) bricks of voxels, stages a brick + halo ONCE in LDS
+// 9 output channels to a 64-wide tile; here a workgroup owns 8x8x8 bricks of voxels, stages a brick + halo ONCE in LDS
 // as bf16 [position][16 channels] (32 B rows) and feeds the MFMA straight from it:
 //   forward / data-gradient:  out[vox, n] = sum_{tap, c} x[vox + tap, c] * w[n, tap, c]
 //       A fragment (voxel rows, 8 consecutive channels of one tap) = ONE 16-byte LDS read; weights [16n][27][16G] in LDS.
@@ -120,7 +120,7 @@ template <int G> struct StencilPitch { static constexpr int HXP = G == 1 ? 16 : 
 // Brick depth = wave count of the workgroup (in the forward kernel a wave owns one z-slice of 64 voxels).  48-channel rows (G = 3, the 36 -> 9
 // layer): with 4 x 8 x 8 bricks the 58 KB halo + 42 KB of weights allowed ONE 4-wave workgroup per CU; 8 x 8 x 8 bricks on 8 waves (96 KB halo)
 // give two waves per SIMD and 1.95 instead of 2.34 halo positions loaded per voxel (forward 1.62 -> 1.15 ms, weight gradient 1.59 -> 1.19 ms).
-template <int G> struct StencilBrick { static constexpr int TZV = G == 3 ? 8 : 4, NTHR = TZV * 64; };   // weight-gradient kernel
+template <int G> struct StencilBrick { static constexpr int TZV = 8, NTHR = TZV * 64; };   // weight-gradient kernel (16-channel rows: 537 -> 495 us against 4 x 8 x 8 on 4 waves)
 // The forward kernels take 8 x 8 x 8 bricks for 16-channel rows too (two 8-wave workgroups per CU, 65 KB of LDS each): 1.95 instead of 2.34 halo
 // positions per voxel; measured against 4 x 8 x 8 on 4 waves x 3 workgroups: 9 -> 9 forward 434 -> 399 us, data gradient 497 -> 471, 9 -> 36 841 -> 765.
 template <int G> struct StencilBrickF { static constexpr int TZV = 8, NTHR = TZV * 64; };
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void stencil_wgrad_fold_kernel(const float* __
 // Brick depth / wave count as in the forward kernel (StencilBrick): 48-channel rows take 8 x 8 x 8 bricks on 8 waves (one workgroup per CU either
 // way: two waves per SIMD instead of one); the NW waves split the 27 taps.
 template <int G, typename AT>
-__global__ __launch_bounds__(StencilBrick<G>::NTHR, G == 1 ? 3 : 2) void stencil3_wgrad_kernel(const StencilWArgsT<AT> p) {
+__global__ __launch_bounds__(StencilBrick<G>::NTHR, 2) void stencil3_wgrad_kernel(const StencilWArgsT<AT> p) {
   constexpr int C = 16 * G, TZV = StencilBrick<G>::TZV, NTHR = StencilBrick<G>::NTHR, NW = NTHR / 64, NTAPW = (27 + NW - 1) / NW;
   constexpr int HPOSV = (TZV + 2) * HY * HX, NVOXV = TZV * TY * TX;
   __shared__ __attribute__((aligned(16))) __bf16 Xs[HPOSV * C];
@@ -562,7 +562,7 @@ static int resident_per_cu(const void* kernel, int threads = 256) {
 }
 
 static int stencil_check(int I, int D, int H, int W) {
-  SV_REQUIRE(I > 0 && D % TZ == 0 && H % TY == 0 && W % TX == 0, "stencil3: grid %dx%dx%d must be a multiple of the 4x8x8 brick", D, H, W);
+  SV_REQUIRE(I > 0 && D % 8 == 0 && H % TY == 0 && W % TX == 0, "stencil3: grid %dx%dx%d must be a multiple of the 8x8x8 brick", D, H, W);
   return SV_OK;
 }
 
@@ -585,8 +585,7 @@ extern "C" int sv_stencil3_fwd(const void* x, int ldx, int cin_load, int groups,
              "stencil3_fwd: planar output needs col_off == 0, no residual and whole planes of ldc (multiple of 4) columns");
   SV_REQUIRE_ACT(act_dtype);
   if (int rc = stencil_check(I, D, H, W)) return rc;
-  SV_REQUIRE(D % 8 == 0, "stencil3_fwd: the forward kernels walk 8x8x8 bricks (D = %d)", D);
-  SV_REQUIRE(cin_load % 4 == 0 && cin_load <= 16 * groups && ldx % 4 == 0 && (x_plane_stride ? cin_load % ldx == 0 : ldx >= cin_load),
+    SV_REQUIRE(cin_load % 4 == 0 && cin_load <= 16 * groups && ldx % 4 == 0 && (x_plane_stride ? cin_load % ldx == 0 : ldx >= cin_load),
              "stencil3_fwd: bad input channels (cin_load=%d ldx=%d groups=%d)", cin_load, ldx, groups);
   SV_REQUIRE(cout > 0 && cout <= 16 * ntiles16 && (out_plane_stride || ldc >= col_off + cout), "stencil3_fwd: bad output window");
   SV_REQUIRE(!stats || ntiles16 == 1, "stencil3_fwd: statistics need a single 16-column tile");
@@ -627,8 +626,7 @@ extern "C" int sv_stencil3_wgrad(const void* x, int ldx, int cin_load, int group
   SV_REQUIRE(cout > 0 && cout <= 16 && cin > 0 && c_stride > 0 && c_valid > 0, "stencil3_wgrad: bad channel counts");
   SV_REQUIRE((((uintptr_t)x | (uintptr_t)dy) & (act_dtype == SV_BF16 ? 7 : 15)) == 0, "stencil3_wgrad: operands must be aligned to 4 elements");
   SV_REQUIRE(groups == 1 || groups == 3, "stencil3_wgrad: unsupported groups=%d", groups);
-  SV_REQUIRE(groups != 3 || D % 8 == 0, "stencil3_wgrad: the 48-channel kernel walks 8x8x8 bricks (D = %d)", D);
-  const int ntiles = I * (D / (groups == 3 ? StencilBrick<3>::TZV : StencilBrick<1>::TZV)) * (H / TY) * (W / TX);
+    const int ntiles = I * (D / (groups == 3 ? StencilBrick<3>::TZV : StencilBrick<1>::TZV)) * (H / TY) * (W / TX);
   hipStream_t s = (hipStream_t)stream;
   SV_DISPATCH_ACT(act_dtype,
     const int per_cu = groups == 1 ? resident_per_cu((const void*)stencil3_wgrad_kernel<1, AT>, StencilBrick<1>::NTHR)
