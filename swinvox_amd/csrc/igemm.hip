@@ -1452,6 +1452,7 @@ __global__ __launch_bounds__(GW_NTHR, 3) void wgrad_wide_kernel(const WGradWideA
 typedef Tile<4, 2, 2, 2> WTileDefault;   // 128 anchor channels x 64 (tap, gathered channel), 8 waves
 typedef Tile<1, 4, 1, 2> WTileNarrow;    // 16 x 128 for <=16 anchor channels
 typedef Tile<2, 4, 4, 2> WTileWide;      // 128 x 128, 8 waves
+typedef Tile<2, 4, 2, 2> WTile64;        // 64 x 128, 8 waves: layers with <= 64 anchor channels (half of a 128-row tile would multiply zeros)
 
 }  // namespace sv
 
@@ -1583,7 +1584,9 @@ extern "C" int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, 
   }
   const bool narrow = g->Co <= 16;
   const bool wide = !narrow && Kout >= 128;      // 128 x 128 tile: the anchor operand is re-read once per 128 (tap, channel) columns
-  const int BMw = narrow ? WTileNarrow::BM : WTileDefault::BM;
+  static const int tile64_on = [] { const char* v = getenv("SV_WGRAD_TILE64"); return v ? atoi(v) : 1; }();
+  const bool t64 = tile64_on && !narrow && wide && g->Co <= 64;
+  const int BMw = narrow ? WTileNarrow::BM : (t64 ? WTile64::BM : WTileDefault::BM);
   const int BNw = narrow ? WTileNarrow::BN : (wide ? WTileWide::BN : WTileDefault::BN);
   const int BKs = math == SV_MATH_BF16 ? 64 : 32;
   const int tiles = cdiv(g->Co, BMw) * cdiv(Kout, BNw);
@@ -1615,6 +1618,7 @@ extern "C" int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, 
     else hipLaunchKernelGGL((wgrad_kernel<true, TL, __bf16, 4>), grid, dim3(TL::NTHR), 0, s, a);                       \
   } while (0)
   if (narrow) SV_LAUNCH_WG(WTileNarrow);
+  else if (t64) SV_LAUNCH_WG(WTile64);
   else if (wide) SV_LAUNCH_WG(WTileWide);
   else SV_LAUNCH_WG(WTileDefault);
 #undef SV_LAUNCH_WG
