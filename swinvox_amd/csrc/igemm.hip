@@ -1453,6 +1453,7 @@ typedef Tile<4, 2, 2, 2> WTileDefault;   // 128 anchor channels x 64 (tap, gathe
 typedef Tile<1, 4, 1, 2> WTileNarrow;    // 16 x 128 for <=16 anchor channels
 typedef Tile<2, 4, 4, 2> WTileWide;      // 128 x 128, 8 waves
 typedef Tile<2, 4, 2, 2> WTile64;        // 64 x 128, 8 waves: layers with <= 64 anchor channels (half of a 128-row tile would multiply zeros)
+typedef Tile<2, 4, 3, 2> WTile96;        // 96 x 128, 8 waves: anchor channel counts 96 k that are not multiples of 128 (Swin stage 0)
 
 }  // namespace sv
 
@@ -1586,7 +1587,8 @@ extern "C" int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, 
   const bool wide = !narrow && Kout >= 128;      // 128 x 128 tile: the anchor operand is re-read once per 128 (tap, channel) columns
   static const int tile64_on = [] { const char* v = getenv("SV_WGRAD_TILE64"); return v ? atoi(v) : 1; }();
   const bool t64 = tile64_on && !narrow && wide && g->Co <= 64;
-  const int BMw = narrow ? WTileNarrow::BM : (t64 ? WTile64::BM : WTileDefault::BM);
+  const bool t96 = tile64_on && !narrow && wide && !t64 && g->Co % 96 == 0 && g->Co % 128 != 0;
+  const int BMw = narrow ? WTileNarrow::BM : (t64 ? WTile64::BM : (t96 ? WTile96::BM : WTileDefault::BM));
   const int BNw = narrow ? WTileNarrow::BN : (wide ? WTileWide::BN : WTileDefault::BN);
   const int BKs = math == SV_MATH_BF16 ? 64 : 32;
   const int tiles = cdiv(g->Co, BMw) * cdiv(Kout, BNw);
@@ -1619,6 +1621,7 @@ extern "C" int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, 
   } while (0)
   if (narrow) SV_LAUNCH_WG(WTileNarrow);
   else if (t64) SV_LAUNCH_WG(WTile64);
+  else if (t96) SV_LAUNCH_WG(WTile96);
   else if (wide) SV_LAUNCH_WG(WTileWide);
   else SV_LAUNCH_WG(WTileDefault);
 #undef SV_LAUNCH_WG
