@@ -806,23 +806,28 @@ __global__ __launch_bounds__((2 * WM + NPROD) * 64, 3) void gemm_wide_kernel(con
 #pragma unroll
         for (int j = 0; j < 4; ++j) bias[nt][j] = (e.bias && colok[nt]) ? e.bias[nbase + nt * 16 + j] : 0.f;
       }
+      // the wave-private 8-row x 128-byte LDS patch that turns the accumulator layout (lane = a row, 8 bytes) into whole 128-byte rows
+      // (16 bytes per lane) and back: 16-byte pairs XOR-swizzled by the row, conflict-free both ways, no barrier (a wave's LDS operations
+      // execute in order)
+      typedef __attribute__((address_space(3))) char lds_char;
+      lds_char* stg = (lds_char*)(smem + GW_STAGES * GW_STAGE_BYTES + 64) + wave * 1024;
+      const int wrow = lr & 7, half_of_lane = lr >> 3, rrow = lane >> 3;
+      const int roff = rrow * 128 + (((lane & 7) ^ rrow) << 4);
+      const int ncol_s = col0 + wn * 64 + (lane & 7) * 8;
       float rsc[4];
-      bf16x4 aux[4][4];                                    // residual OR activation-gradient source (gemm_wide_ok: never both)
+      bf16x8 raw[4][2];                                    // residual OR activation-gradient source rows (gemm_wide_ok: never both), whole lines
       if constexpr (GENERAL) {
+        const __bf16* src = e.residual ? static_cast<const __bf16*>(e.residual) + ncol_s : static_cast<const __bf16*>(e.act_grad_src) + e.col_off + ncol_s;
+        const int lds_ = e.residual ? e.ldr : e.ldc;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const int m = mbase + mt * 16;
-          const bool rowok = m < Mrows;
-          rsc[mt] = (rowok && e.residual && e.row_scale) ? e.row_scale[m / e.rows_per_scale] : 1.f;
+          rsc[mt] = (m < Mrows && e.residual && e.row_scale) ? e.row_scale[m / e.rows_per_scale] : 1.f;
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const int n0 = nbase + nt * 16;
-            aux[mt][nt] = VecN<__bf16, 4>::zero();
-            if (rowok && colok[nt]) {
-              const __bf16* src = e.residual ? static_cast<const __bf16*>(e.residual) + (size_t)m * e.ldr + n0
-                                             : static_cast<const __bf16*>(e.act_grad_src) + (size_t)m * e.ldc + e.col_off + n0;
-              aux[mt][nt] = *reinterpret_cast<const bf16x4*>(src);
-            }
+          for (int h = 0; h < 2; ++h) {
+            const int ms = row0 + wm * 64 + mt * 16 + h * 8 + rrow;
+            raw[mt][h] = VecN<__bf16, 8>::zero();
+            if (ms < Mrows && ncol_s < g.Co) raw[mt][h] = *reinterpret_cast<const bf16x8*>(src + (size_t)ms * lds_);
           }
         }
       }
@@ -831,14 +836,9 @@ __global__ __launch_bounds__((2 * WM + NPROD) * 64, 3) void gemm_wide_kernel(con
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s1[nt][j] = 0.f; s2[nt][j] = 0.f; }
-      // stores: a lane holds 8 bytes of a row; through a wave-private 8-row x 128-byte LDS patch (16-byte pairs XOR-swizzled by the row:
-      // conflict-free both ways) they become 16 bytes per lane, 8 whole 128-byte rows per instruction - a quarter of the cache lines
-      // touched per byte of the 8-byte form (measured: the partial-line stores cost as much as the K loop at K = 384)
-      typedef __attribute__((address_space(3))) char lds_char;
-      lds_char* stg = (lds_char*)(smem + GW_STAGES * GW_STAGE_BYTES + 64) + wave * 1024;
-      const int wrow = lr & 7, half_of_lane = lr >> 3, rrow = lane >> 3;
-      const int roff = rrow * 128 + (((lane & 7) ^ rrow) << 4);
-      const int ncol_s = col0 + wn * 64 + (lane & 7) * 8;
+      // stores: through the patch a lane's 8 bytes of a row become 16 bytes per lane, 8 whole 128-byte rows per instruction - a quarter of the
+      // cache lines touched per byte of the 8-byte form (measured: the partial-line stores cost as much as the K loop at K = 384); the
+      // residual / activation-gradient rows come in the same way (above)
       auto rows_out = [&](__bf16* dst, const bf16x4 (&ob)[4], int mt) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -860,7 +860,20 @@ __global__ __launch_bounds__((2 * WM + NPROD) * 64, 3) void gemm_wide_kernel(con
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const bool rowok = mbase + mt * 16 < Mrows;
-        bf16x4 ob[4], pb[4];
+        bf16x4 ob[4], pb[4], aux[4];
+        if constexpr (GENERAL) {   // whole rows -> patch -> this lane's four 8-byte pieces
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<__attribute__((address_space(3))) bf16x8*>(stg + roff) = raw[mt][h];
+            __builtin_amdgcn_wave_barrier();
+            if (half_of_lane == h) {
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt)
+                aux[nt] = *reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(stg + wrow * 128 + (((nt * 4 + lg) ^ (2 * wrow)) << 3));
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           float v[4];
@@ -869,7 +882,7 @@ __global__ __launch_bounds__((2 * WM + NPROD) * 64, 3) void gemm_wide_kernel(con
           if constexpr (GENERAL) {
             if (e.act_grad_src) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] *= act_grad_t<true>((float)aux[mt][nt][j], e.act_grad_kind, e.slope);
+              for (int j = 0; j < 4; ++j) v[j] *= act_grad_t<true>((float)aux[nt][j], e.act_grad_kind, e.slope);
             }
           }
 #pragma unroll
@@ -879,7 +892,7 @@ __global__ __launch_bounds__((2 * WM + NPROD) * 64, 3) void gemm_wide_kernel(con
           if constexpr (GENERAL) {
             if (e.residual) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = (float)aux[mt][nt][j] + rsc[mt] * v[j];
+              for (int j = 0; j < 4; ++j) v[j] = (float)aux[nt][j] + rsc[mt] * v[j];
             }
           }
 #pragma unroll
@@ -1221,6 +1234,7 @@ static bool gemm_wide_ok(const IGemmArgs& a, long long M) {
   // where it wins (scripts/bench_gemm_wide.py, M = 25k .. 400k): everything from K = 192 on, except the BatchNorm producers (two double
   // atomics per column and 64 rows), which need a K loop long enough to carry them
   if (enabled == 1 && e.stats && K < 1024) return false;
+  if (enabled == 1 && e.act_grad_src && K < 384) return false;   // 192 -> 768 with GELU': 573 us against 522 on the 128-wide kernel
   if (((e.ldc | e.col_off | Co) & 7) || (e.residual && (e.ldr & 7))) return false;
   // the general epilogue variant keeps no statistics registers and one set of prefetched rows (residual OR activation-gradient source)
   if ((e.stats && (e.residual || e.act_grad_src)) || (e.residual && e.act_grad_src)) return false;
