@@ -17,7 +17,7 @@ from swinvox_amd import hip  # noqa: E402
 from swinvox_amd.ops import ACT_GELU, ConvSpec  # noqa: E402
 
 SHAPES = [  # M, K, N, epilogue
-    (401408, 768, 192, "resscale"), (401408, 768, 192, ""), (401408, 192, 768, "gelu"), (401408, 192, 768, "agelu"), (1605632, 384, 192, ""),
+    (100352, 384, 1536, "agelu"), (401408, 768, 192, "resscale"), (401408, 768, 192, ""), (401408, 192, 768, "gelu"), (401408, 192, 768, "agelu"), (1605632, 384, 192, ""),
     (100352, 1536, 384, "agelu"), (100352, 1536, 384, "resscale"), (100352, 1024, 256, "arelu"), (100352, 1024, 256, "stats"), (25088, 3072, 768, "agelu"),
     (100352, 384, 1536, "gelu"), (100352, 1536, 384, "res"), (100352, 384, 1152, "bias"), (100352, 384, 384, "res"), (100352, 1536, 384, ""),
     (100352, 384, 1536, ""), (25088, 768, 3072, "gelu"), (25088, 3072, 768, "res"), (25088, 768, 2304, "bias"), (25088, 768, 768, "res"),

@@ -153,6 +153,30 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
   const float qd = fmaf(x2, fmaf(x2, -3.45720919e-03f, 2.21791923e-01f), 1.59511919f);     // d/dx [x (c0 + c1 x^2 + c2 x^4)]
   return s * fmaf(x * (1.f - s), qd, 1.f);
 }
+// the same on PAIRS of values: the polynomial parts run as packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 do two lanes-worth per
+// instruction), only min / exp / rcp stay per element: 17 instructions per pair instead of ~15 per element
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_sigma2(f32x2 x, f32x2& x2) {   // sigma(x (c0 + c1 x^2 + c2 x^4)), x2 = min(x^2, 64)
+  x2 = x * x;
+  x2[0] = fminf(x2[0], 64.f); x2[1] = fminf(x2[1], 64.f);
+  const f32x2 p = __builtin_elementwise_fma(x2, __builtin_elementwise_fma(x2, (f32x2)(9.975397e-04f), (f32x2)(-1.0665937e-01f)), (f32x2)(-2.3012706e+00f));
+  const f32x2 xp = x * p;
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(xp[0]); e[1] = __builtin_amdgcn_exp2f(xp[1]);
+  e = e + (f32x2)(1.f);
+  f32x2 s;
+  s[0] = __builtin_amdgcn_rcpf(e[0]); s[1] = __builtin_amdgcn_rcpf(e[1]);
+  return s;
+}
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) { f32x2 x2; return x * gelu_sigma2(x, x2); }
+__device__ __forceinline__ void gelu_both_fast2(f32x2 x, f32x2& g, f32x2& dg) {
+  f32x2 x2;
+  const f32x2 s = gelu_sigma2(x, x2);
+  const f32x2 qd = __builtin_elementwise_fma(x2, __builtin_elementwise_fma(x2, (f32x2)(-3.45720919e-03f), (f32x2)(2.21791923e-01f)), (f32x2)(1.59511919f));
+  g = x * s;
+  dg = s * __builtin_elementwise_fma(x * ((f32x2)(1.f) - s), qd, (f32x2)(1.f));
+}
+__device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) { f32x2 g, dg; gelu_both_fast2(x, g, dg); return dg; }
 template <bool FAST> __device__ __forceinline__ float gelu_t(float x) {
   if constexpr (FAST) return gelu_fast(x);
   else return gelu_erf(x);

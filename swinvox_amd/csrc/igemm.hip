@@ -229,12 +229,28 @@ __device__ __forceinline__ void epilogue_rows(const IGemmArgs& p, const ClassInf
         if (e.act_grad_src) {
           float a[CV];
           ldnf<CV>(static_cast<const AT*>(e.act_grad_src) + o, a);
+          if (BF16 && e.act_grad_kind == SV_ACT_GELU) {      // pairs: packed fp32 math (common.h)
 #pragma unroll
-          for (int j = 0; j < CV; ++j) v[j] *= act_grad_t<BF16>(a[j], e.act_grad_kind, e.slope);
+            for (int j = 0; j < CV; j += 2) {
+              const f32x2 dg = gelu_grad_fast2((f32x2){a[j], a[j + 1]});
+              v[j] *= dg[0]; v[j + 1] *= dg[1];
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < CV; ++j) v[j] *= act_grad_t<BF16>(a[j], e.act_grad_kind, e.slope);
+          }
         }
         if (e.pre_act) stnf<CV>(static_cast<AT*>(e.pre_act) + o, v);
+        if (BF16 && e.act == SV_ACT_GELU) {
 #pragma unroll
-        for (int j = 0; j < CV; ++j) v[j] = apply_act_t<BF16>(v[j], e.act, e.slope);
+          for (int j = 0; j < CV; j += 2) {
+            const f32x2 gl = gelu_fast2((f32x2){v[j], v[j + 1]});
+            v[j] = gl[0]; v[j + 1] = gl[1];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < CV; ++j) v[j] = apply_act_t<BF16>(v[j], e.act, e.slope);
+        }
         if (e.residual) {
           float r[CV];
           ldnf<CV>(static_cast<const AT*>(e.residual) + (size_t)pos * e.ldr + n0, r);
@@ -881,14 +897,30 @@ __global__ __launch_bounds__((2 * WM + NPROD) * 64, 3) void gemm_wide_kernel(con
           for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j] + bias[nt][j];
           if constexpr (GENERAL) {
             if (e.act_grad_src) {
+              if (e.act_grad_kind == SV_ACT_GELU) {        // pairs: packed fp32 math (common.h)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] *= act_grad_t<true>((float)aux[nt][j], e.act_grad_kind, e.slope);
+                for (int j = 0; j < 4; j += 2) {
+                  const f32x2 dg = gelu_grad_fast2((f32x2){(float)aux[nt][j], (float)aux[nt][j + 1]});
+                  v[j] *= dg[0]; v[j + 1] *= dg[1];
+                }
+              } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= act_grad_t<true>((float)aux[nt][j], e.act_grad_kind, e.slope);
+              }
             }
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) pb[nt][j] = (__bf16)v[j];
+          if (e.act == SV_ACT_GELU) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = apply_act_t<true>(v[j], e.act, e.slope);
+            for (int j = 0; j < 4; j += 2) {
+              const f32x2 gl = gelu_fast2((f32x2){v[j], v[j + 1]});
+              v[j] = gl[0]; v[j + 1] = gl[1];
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = apply_act_t<true>(v[j], e.act, e.slope);
+          }
           if constexpr (GENERAL) {
             if (e.residual) {
 #pragma unroll

@@ -66,6 +66,20 @@ __global__ __launch_bounds__(256) void swin_mlp_pack_kernel(const float* __restr
 // 6 VALU + v_exp_f32 + v_rcp_f32 against 16 + 2 for erf by Abramowitz-Stegun 7.1.26 - with 16 activations per lane behind every 12 MFMAs
 // (C = 96) the GELU stream, not the matrix pipe, paced these kernels (probe: forward 0.36 ms with A&S, 0.22 ms with GELU compiled out).
 // The exact-fp32 parity mode never comes here (erff in the unfused chain).
+__device__ __forceinline__ f32x2 gelu_pair(f32x2 x) {
+#if defined(SV_PROBE_NOGELU)
+  return x;
+#else
+  return gelu_fast2(x);
+#endif
+}
+__device__ __forceinline__ void gelu_both_pair(f32x2 x, f32x2& g, f32x2& dg) {
+#if defined(SV_PROBE_NOGELU)
+  g = x; dg = (f32x2)(1.f); return;
+#else
+  gelu_both_fast2(x, g, dg);
+#endif
+}
 __device__ __forceinline__ float gelu_fwd(float x) {
 #if defined(SV_PROBE_NOGELU)   // measurement probe only (never built into the library)
   return x;
@@ -225,9 +239,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void swin_mlp_fwd_kernel(const MlpArg
     for (int sub = 0; sub < 2; ++sub) {
       const int hid0 = (2 * pr + sub) * 32;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float v = acc1[sub][i] + sb1[hid0 + (i & 3) + 8 * (i >> 2) + 4 * h];
-        acc1[sub][i] = gelu_fwd(v);
+      for (int i = 0; i < 16; i += 2) {      // pairs: packed fp32 math (common.h gelu_fast2)
+        const int hb = hid0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const f32x2 gl = gelu_pair((f32x2){acc1[sub][i] + sb1[hb], acc1[sub][i + 1] + sb1[hb + 1]});
+        acc1[sub][i] = gl[0]; acc1[sub][i + 1] = gl[1];
       }
       hb[sub][0] = pack8(acc1[sub], 0); hb[sub][1] = pack8(acc1[sub], 1);
     }
@@ -362,10 +377,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void swin_mlp_bwd_kernel(const MlpArg
         }
         const int hid0 = (2 * pr + sub) * 32;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float g, dg;
-          gelu_both(acc1[i] + sb1[hid0 + (i & 3) + 8 * (i >> 2) + 4 * h], g, dg);
-          accd[i] *= dg;
+        for (int i = 0; i < 16; i += 2) {
+          const int hb = hid0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          f32x2 g, dg;
+          gelu_both_pair((f32x2){acc1[i] + sb1[hb], acc1[i + 1] + sb1[hb + 1]}, g, dg);
+          accd[i] *= dg[0]; accd[i + 1] *= dg[1];
         }
         const bf16x8 d0 = pack8(accd, 0), d1 = pack8(accd, 1);
         __builtin_amdgcn_sched_barrier(0);               // do not hoist the next fragments above the GELU block (register pressure)
@@ -608,12 +624,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void swin_mlp_wgrad_kernel(c
             d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[f], w2b[hb][f], d, 0, 0, 0);
           }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float g, dg;
-            gelu_both(a[i] + b1v[hb], g, dg);
-            a[i] = g;
-            d[i] *= dg;
-            db1acc[hb] += d[i];
+          for (int i = 0; i < 4; i += 2) {
+            f32x2 g, dg;
+            gelu_both_pair((f32x2){a[i] + b1v[hb], a[i + 1] + b1v[hb]}, g, dg);
+            a[i] = g[0]; a[i + 1] = g[1];
+            d[i] *= dg[0]; d[i + 1] *= dg[1];
+            db1acc[hb] += d[i] + d[i + 1];
           }
           Hh[tb][hb] = a; Dh[tb][hb] = d;
         }
