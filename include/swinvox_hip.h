@@ -262,6 +262,20 @@ int sv_swin_mlp_wgrad(const void* x1, const void* dx2, const float* ln_g, const 
                       const float* b1, const float* row_scale, int rows_per_scale, float* dw1, float* db1, float* dw2, float* db2,
                       long long M, int C, float eps, void* stream);
 
+/* Fused attention branch of a stage-0 Swin block (timm SwinTransformerBlock._attn + the residual of forward(), reached from
+ * models/swin_transformer.py:78): x1 = x + row_scale * proj(window_attention(qkv(LayerNorm(x)))) in one kernel, the roll / 7x7 partition /
+ * reverse and the shift mask folded into token index math as in sv_window_attention_fwd.  Built for C = 96, 3 heads, bf16 token rows
+ * (sv_swin_attn_block_supported): both weight matrices stay in LDS for the lifetime of a workgroup.
+ *  x, x1: [I*H*W, C] bf16;  ln_g / ln_b [C], wqkv [3C, C], bqkv [3C], table [169, heads], wproj [C, C], bproj [C]: fp32 parameters in their
+ *  native layouts;  row_scale (may be NULL): one drop-path factor per image.
+ *  Side outputs for the (unfused) backward, all or none: ln1 [M, C] bf16 + mean / rstd [M] fp32 (LayerNorm output and statistics),
+ *  qkv [M, 3C] bf16, att [M, C] bf16 (head outputs before the projection) - the tensors sv_layernorm_fwd, the qkv linear and
+ *  sv_window_attention_fwd would have stored.                                                                                          */
+int sv_swin_attn_block_supported(int C, int heads, int act_dtype, int math);
+int sv_swin_attn_block_fwd(const void* x, const float* ln_g, const float* ln_b, const float* wqkv, const float* bqkv, const float* table,
+                           const float* wproj, const float* bproj, const float* row_scale, void* x1, void* ln1, float* mean, float* rstd,
+                           void* qkv, void* att, int I, int H, int W, int C, int heads, int shift, float eps, int act_dtype, void* stream);
+
 /* Layout kernels of the ResNet stem (models/encoder.py:22: Conv2d(3, 64, 7, stride 2, pad 3) as a 4x4 / stride-1 convolution on the
  * space-to-depth image [I][112][112][(sy, sx, c) = 16]) and of the merger's stencil weights (merger.py:20-54):
  *  sv_stem_space_to_depth: images [I,3,224,224] -> x16;  sv_stem_pack: w [64,3,7,7] fp32 -> [64][16 taps][16] (out_dtype);

@@ -23,6 +23,8 @@ def family(name: str) -> str:
                 return "fused Swin MLP: " + k
     if "igemm_kernel" in n or ("wgrad_kernel" in n and "stencil" not in n) or "gemm_dense_kernel" in n or "gemm_wide_kernel" in n or "wgrad_wide_kernel" in n:
         return "contraction engine (igemm_kernel + gemm_dense_kernel + gemm_wide_kernel + wgrad_kernel + wgrad_wide_kernel)"
+    if "swin_attn_block_fwd" in n:
+        return "fused Swin attention branch forward (swin_attn_block_fwd_kernel)"
     if "win_attn_fwd" in n:
         return "window attention forward (win_attn_fwd_*)"
     if "win_attn_bwd" in n:

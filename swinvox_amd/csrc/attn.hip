@@ -1024,6 +1024,251 @@ __global__ __launch_bounds__(256) void attn_dtable_fold_kernel(const float* __re
   dtable[i] += a;
 }
 
+
+// ---- fused attention branch of a stage-0 Swin block (C = 96, 3 heads) ----------------------------------------------------------------
+// x1 = x + s * proj(window_attention(qkv(LayerNorm(x)))) in ONE kernel (timm SwinTransformerBlock behind models/swin_transformer.py:78:
+// norm1 -> roll / partition -> qkv -> per-head softmax(q k^T * scale + bias (+ mask)) v -> proj -> reverse / roll -> drop-path -> + x).
+// At C = 96 both weight matrices fit LDS as bf16 (288 x 96 + 96 x 96 = 72 KB), so a workgroup stages them once and then walks windows:
+// 8 waves = 2 windows in flight, the 4 waves of a window own 16 token rows each (49 tokens padded to 64).
+//  * LayerNorm runs on the MFMA operand layout itself: a lane loads the 16-byte chunks (token lr, channels 32 ks + 8 lg ..) that ARE its
+//    fragment of the qkv GEMM, the row sums cross the four lane groups with two shuffles - the normalised rows never touch LDS.
+//  * every product is taken with the operands swapped (weights / keys / V^T as the first MFMA operand), so the accumulator of a lane is
+//    4 consecutive channels (or keys) of ONE token: q | k | v go to the LDS tile and to HBM as 8-byte vectors, and the softmax of a query
+//    is 16 in-lane values + two shuffles across the lane groups instead of 16-lane reductions per accumulator row.
+//  * the probabilities never leave registers: S^T = K Q^T leaves keys (16 nt + 4 lg + j) in the lane that, as the second operand of
+//    P V, must supply 8 keys per K step - the contraction index of an MFMA may be permuted freely as long as both operands agree, so the
+//    V^T fragment is fetched with ds_read_b64_tr_b16 from exactly those key rows (two 4-row blocks of the row-major V tile).
+//  * the head outputs overwrite the (wave-private) q columns of the tile and become the operand of the projection; the residual, the
+//    projection bias and the per-image drop-path factor are applied on the accumulators.
+// Training needs the intermediate tensors of the unfused chain for its backward (LayerNorm output + statistics, qkv, attention output):
+// they are written as side outputs when their pointers are given, bit-identical to what the unfused kernels store (q is rounded to bf16
+// before the softmax scale is applied, as the core kernel does with the q it reads back), 7 instead of 13 passes over the token map;
+// without them (inference) the kernel reads x and writes x1.  Two barriers per window; the next window's rows are prefetched into
+// registers before the attention phase.
+constexpr int FB_C = 96, FB_HEADS = 3;
+constexpr int FB_LDT = 296;   // bf16 row stride of the q | k | v tile: 592 bytes = 37 x 16, odd -> 16-byte fragment reads of 16 rows spread over all bank groups
+constexpr int FB_LDW = 104;   // bf16 row stride of the weight images: 208 bytes = 13 x 16
+struct BlockFwdArgs {
+  const __bf16* x; const float *ln_g, *ln_b, *wqkv, *bqkv, *table, *wproj, *bproj, *row_scale;
+  __bf16 *x1, *ln1, *qkv, *att; float *mean, *rstd;
+  int I, H, W, shift; float eps, scale; int ntasks, tasks_per_group;
+};
+constexpr int FB_SMEM = (288 + 96) * FB_LDW * 2 + 2 * 64 * FB_LDT * 2 + (3 * 176 + 288 + 3 * 96) * 4;
+
+__global__ __launch_bounds__(512, 1) void swin_attn_block_fwd_kernel(const BlockFwdArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char fb_smem[FB_SMEM];
+  __bf16* Wq = reinterpret_cast<__bf16*>(fb_smem);          // [288][FB_LDW]  qkv.weight rows (out, in)
+  __bf16* Wp = Wq + 288 * FB_LDW;                            // [96][FB_LDW]   proj.weight rows
+  __bf16* Tb = Wp + 96 * FB_LDW;                             // 2 x [64][FB_LDT]  q (-> O) | k | v of the two windows in flight
+  float* bt = reinterpret_cast<float*>(Tb + 2 * 64 * FB_LDT);   // [3][176] relative-position bias table per head, times log2 e
+  float* bq = bt + 3 * 176;                                  // [288] qkv bias
+  float* bp = bq + 288;                                      // [96] proj bias
+  float* lng = bp + 96;                                      // [96] norm1 weight
+  float* lnb = lng + 96;                                     // [96] norm1 bias
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;
+  const int lr = lane & 15, lg = lane >> 4;
+  for (int i = tid; i < 288 * 24; i += 512) {
+    const int n = i / 24, c4 = (i - n * 24) * 4;
+    const float4 w = ld4f(p.wqkv + n * FB_C + c4);
+    bf16x4 b; b[0] = (__bf16)w.x; b[1] = (__bf16)w.y; b[2] = (__bf16)w.z; b[3] = (__bf16)w.w;
+    *reinterpret_cast<bf16x4*>(Wq + n * FB_LDW + c4) = b;
+  }
+  for (int i = tid; i < 96 * 24; i += 512) {
+    const int n = i / 24, c4 = (i - n * 24) * 4;
+    const float4 w = ld4f(p.wproj + n * FB_C + c4);
+    bf16x4 b; b[0] = (__bf16)w.x; b[1] = (__bf16)w.y; b[2] = (__bf16)w.z; b[3] = (__bf16)w.w;
+    *reinterpret_cast<bf16x4*>(Wp + n * FB_LDW + c4) = b;
+  }
+  for (int i = tid; i < 3 * 169; i += 512) { const int h = i / 169, e = i - h * 169; bt[h * 176 + e] = p.table[e * FB_HEADS + h] * ATTN_LOG2E; }
+  for (int i = tid; i < 288; i += 512) bq[i] = p.bqkv[i];
+  if (tid < 96) { bp[tid] = p.bproj[tid]; lng[tid] = p.ln_g[tid]; lnb[tid] = p.ln_b[tid]; }
+  __syncthreads();
+
+  const int q = wave * 16 + lr;                      // the token (query) of this lane in every transposed accumulator
+  const bool qok = q < WT;
+  // relative-position bias of this lane's 16 (query, key) slots per head: the same for every window
+  float bias[FB_HEADS][4][4];
+  {
+    const int qy = q / 7, qx = q - qy * 7;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = nt * 16 + lg * 4 + j, ky = key / 7, kx = key - ky * 7;
+#pragma unroll
+        for (int h = 0; h < FB_HEADS; ++h)
+          bias[h][nt][j] = key >= WT ? -1.0e30f : (qok ? bt[h * 176 + (qy - ky + 6) * 13 + (qx - kx + 6)] : 0.f);
+      }
+  }
+  __bf16* T = Tb + grp * 64 * FB_LDT;
+  const int nWx = p.W / 7, nW = (p.H / 7) * nWx;
+  const long long task0 = ((long long)blockIdx.x * 2 + grp) * p.tasks_per_group;
+  const float qscale = p.scale * ATTN_LOG2E;
+  const bf16x8 zero8 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+
+  bf16x8 xr[3] = {zero8, zero8, zero8};
+  auto fetch = [&](long long task) {                  // this lane's three 16-byte chunks of its token row of window `task`
+    xr[0] = zero8; xr[1] = zero8; xr[2] = zero8;
+    if (task < p.ntasks && qok) {
+      const TokMap tmn = task_map(task, nW, nWx, p.H, p.W, p.shift);
+      const __bf16* src = p.x + (size_t)tmn.row(q) * FB_C + lg * 8;
+      xr[0] = *reinterpret_cast<const bf16x8*>(src); xr[1] = *reinterpret_cast<const bf16x8*>(src + 32); xr[2] = *reinterpret_cast<const bf16x8*>(src + 64);
+    }
+  };
+  fetch(task0);
+  for (int tt = 0; tt < p.tasks_per_group; ++tt) {
+    const long long task = task0 + tt;
+    const bool live = task < p.ntasks;                                   // uniform over the 4 waves of a window
+    const TokMap tm = task_map(live ? task : 0, nW, nWx, p.H, p.W, p.shift);
+    const bool valid = live && qok;
+    const size_t row = (size_t)tm.row(qok ? q : 0);
+    // ---- LayerNorm of the wave's 16 rows, on the operand layout
+    bf16x8 xf[3];
+    {
+      float xv[3][8];
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xv[ks][e] = (float)xr[ks][e]; s += xv[ks][e]; }
+      s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+      const float mean = s * (1.f / FB_C);
+      float v2 = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float a = xv[ks][e] - mean; v2 += a * a; }
+      v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
+      const float rstd = rsqrtf(v2 * (1.f / FB_C) + p.eps);
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const float4 g0 = *reinterpret_cast<const float4*>(lng + ks * 32 + lg * 8), g1 = *reinterpret_cast<const float4*>(lng + ks * 32 + lg * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(lnb + ks * 32 + lg * 8), b1 = *reinterpret_cast<const float4*>(lnb + ks * 32 + lg * 8 + 4);
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xf[ks][e] = (__bf16)((xv[ks][e] - mean) * rstd * g[e] + b[e]);
+      }
+      if (valid && p.ln1) {
+        __bf16* dst = p.ln1 + row * FB_C + lg * 8;
+        *reinterpret_cast<bf16x8*>(dst) = xf[0]; *reinterpret_cast<bf16x8*>(dst + 32) = xf[1]; *reinterpret_cast<bf16x8*>(dst + 64) = xf[2];
+        if (lg == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+      }
+    }
+    fetch(tt + 1 < p.tasks_per_group ? task + 1 : (long long)p.ntasks);   // lands during the GEMMs below
+    // ---- qkv = LN(x) W^T + b as transposed blocks: lane -> token lr, output columns nb*16 + lg*4 .. +3
+#pragma unroll 2
+    for (int nb = 0; nb < 18; ++nb) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Wq + (nb * 16 + lr) * FB_LDW + ks * 32 + lg * 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xf[ks], acc, 0, 0, 0);
+      }
+      const int n0 = nb * 16 + lg * 4;
+      const float4 bb = *reinterpret_cast<const float4*>(bq + n0);
+      bf16x4 o;
+      o[0] = (__bf16)(acc[0] + bb.x); o[1] = (__bf16)(acc[1] + bb.y); o[2] = (__bf16)(acc[2] + bb.z); o[3] = (__bf16)(acc[3] + bb.w);
+      if (valid && p.qkv) *reinterpret_cast<bf16x4*>(p.qkv + row * (3 * FB_C) + n0) = o;
+      if (nb < 6) {   // q: the softmax scale (and log2 e) goes onto the bf16 value, as the core kernel applies it to the q it reads from HBM
+        o[0] = (__bf16)((float)o[0] * qscale); o[1] = (__bf16)((float)o[1] * qscale); o[2] = (__bf16)((float)o[2] * qscale); o[3] = (__bf16)((float)o[3] * qscale);
+      }
+      *reinterpret_cast<bf16x4*>(T + q * FB_LDT + n0) = o;
+    }
+    __syncthreads();                                                     // all key / value rows of both windows are in LDS
+    // ---- attention, one head at a time; lane -> query lr, keys nt*16 + lg*4 + j
+    const bool masked = p.shift > 0 && (tm.wy == p.H / 7 - 1 || tm.wx == nWx - 1);
+    int qreg = 0; unsigned kdiff = 0;                                    // bit (nt*4 + j): key in another region than the query
+    if (masked) {
+      qreg = qok ? tm.region(q) : 0;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = nt * 16 + lg * 4 + j;
+          if (qok && key < WT && tm.region(key) != qreg) kdiff |= 1u << (nt * 4 + j);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < FB_HEADS; ++h) {
+      f32x4 s[4];
+      {
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(T + q * FB_LDT + h * HD + lg * 8);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(T + (nt * 16 + lr) * FB_LDT + FB_C + h * HD + lg * 8);
+          s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+      }
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = bias[h][nt][j] <= -1.0e29f ? -1.0e30f : s[nt][j] + bias[h][nt][j];
+          if (kdiff & (1u << (nt * 4 + j))) v += -100.0f * ATTN_LOG2E;
+          s[nt][j] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(s[nt][j] - mx); s[nt][j] = e; sum += e; }
+      sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+      bf16x8 pf[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pf[ks][j] = (__bf16)(s[2 * ks][j] * inv); pf[ks][4 + j] = (__bf16)(s[2 * ks + 1][j] * inv); }
+      f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          // V^T fragment: head channel nt*16 + lr, the 8 keys of this lane group in the order the P fragment holds them
+          const __bf16* src = T + (2 * ks * 16 + lg * 4 + (lr >> 2)) * FB_LDT + 2 * FB_C + h * HD + nt * 16 + (lr & 3) * 4;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src + 16 * FB_LDT));
+          const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ks], o[nt], 0, 0, 0);
+        }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {                                   // lane -> query lr, head channels nt*16 + lg*4 .. +3
+        bf16x4 ob;
+        ob[0] = (__bf16)o[nt][0]; ob[1] = (__bf16)o[nt][1]; ob[2] = (__bf16)o[nt][2]; ob[3] = (__bf16)o[nt][3];
+        if (valid && p.att) *reinterpret_cast<bf16x4*>(p.att + row * FB_C + h * HD + nt * 16 + lg * 4) = ob;
+        *reinterpret_cast<bf16x4*>(T + q * FB_LDT + h * HD + nt * 16 + lg * 4) = ob;   // over this wave's own q rows
+      }
+    }
+    __syncthreads();                                                     // keys / values are consumed: the next window may overwrite them
+    // ---- x1 = x + s * (O Wp^T + bp), lane -> token lr, channels nb*16 + lg*4 .. +3
+    {
+      const float sc = p.row_scale ? p.row_scale[tm.img] : 1.f;
+      bf16x8 of[3];
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) of[ks] = *reinterpret_cast<const bf16x8*>(T + q * FB_LDT + ks * 32 + lg * 8);
+#pragma unroll
+      for (int nb = 0; nb < 6; ++nb) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(Wp + (nb * 16 + lr) * FB_LDW + ks * 32 + lg * 8);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, of[ks], acc, 0, 0, 0);
+        }
+        if (valid) {
+          const int n0 = nb * 16 + lg * 4;
+          const float4 bb = *reinterpret_cast<const float4*>(bp + n0);
+          const float4 xres = ld4f(p.x + row * FB_C + n0);
+          st4f(p.x1 + row * FB_C + n0, make_float4(xres.x + sc * (acc[0] + bb.x), xres.y + sc * (acc[1] + bb.y),
+                                                    xres.z + sc * (acc[2] + bb.z), xres.w + sc * (acc[3] + bb.w)));
+        }
+      }
+    }
+  }
+}
+
 }  // namespace sv
 
 using namespace sv;
@@ -1151,4 +1396,34 @@ extern "C" int sv_cross_view_attention_bwd(const void* qkv, const void* dout, vo
                    1.0f / sqrtf((float)(R / heads) * (float)V)};
     hipLaunchKernelGGL(cva_attn_bwd_kernel<AT>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a););
   return check_launch("sv_cross_view_attention_bwd");
+}
+
+// ---- fused attention branch of a stage-0 Swin block ------------------------------------------------------------------------------------
+extern "C" int sv_swin_attn_block_supported(int C, int heads, int act_dtype, int math) {
+  return C == FB_C && heads == FB_HEADS && act_dtype == SV_BF16 && math == SV_MATH_BF16;
+}
+
+extern "C" int sv_swin_attn_block_fwd(const void* x, const float* ln_g, const float* ln_b, const float* wqkv, const float* bqkv, const float* table,
+                                      const float* wproj, const float* bproj, const float* row_scale, void* x1, void* ln1, float* mean,
+                                      float* rstd, void* qkv, void* att, int I, int H, int W, int C, int heads, int shift, float eps,
+                                      int act_dtype, void* stream) {
+  SV_REQUIRE(x && ln_g && ln_b && wqkv && bqkv && table && wproj && bproj && x1 && I > 0, "swin_attn_block_fwd: null/empty argument");
+  SV_REQUIRE(C == FB_C && heads == FB_HEADS && act_dtype == SV_BF16, "swin_attn_block_fwd: built for C = 96, 3 heads, bf16 token rows (got C=%d heads=%d dtype=%d)",
+             C, heads, act_dtype);
+  SV_REQUIRE(H % 7 == 0 && W % 7 == 0 && H >= 7 && W >= 7, "swin_attn_block_fwd: map %dx%d is not a multiple of the 7x7 window", H, W);
+  SV_REQUIRE(shift >= 0 && shift < 7 && (shift == 0 || (H > 7 && W > 7)), "swin_attn_block_fwd: bad shift %d for map %dx%d", shift, H, W);
+  const bool side = ln1 || mean || rstd || qkv || att;
+  SV_REQUIRE(!side || (ln1 && mean && rstd && qkv && att), "swin_attn_block_fwd: the side outputs (ln1, mean, rstd, qkv, att) come all or none");
+  SV_REQUIRE((((uintptr_t)x | (uintptr_t)x1 | (uintptr_t)ln1 | (uintptr_t)qkv | (uintptr_t)att | (uintptr_t)wqkv | (uintptr_t)wproj) & 15) == 0,
+             "swin_attn_block_fwd: tensors must be 16-byte aligned");
+  BlockFwdArgs a{};
+  a.x = static_cast<const __bf16*>(x); a.ln_g = ln_g; a.ln_b = ln_b; a.wqkv = wqkv; a.bqkv = bqkv; a.table = table; a.wproj = wproj; a.bproj = bproj;
+  a.row_scale = row_scale; a.x1 = static_cast<__bf16*>(x1); a.ln1 = static_cast<__bf16*>(ln1); a.qkv = static_cast<__bf16*>(qkv);
+  a.att = static_cast<__bf16*>(att); a.mean = mean; a.rstd = rstd;
+  a.I = I; a.H = H; a.W = W; a.shift = shift; a.eps = eps; a.scale = 1.0f / sqrtf((float)HD);
+  a.ntasks = I * (H / 7) * (W / 7);
+  a.tasks_per_group = cdiv(a.ntasks, 512);                  // one workgroup (two window groups) per CU, every group the same share
+  const int nblocks = cdiv(a.ntasks, 2 * a.tasks_per_group);
+  hipLaunchKernelGGL(swin_attn_block_fwd_kernel, dim3(nblocks), dim3(512), 0, (hipStream_t)stream, a);
+  return check_launch("sv_swin_attn_block_fwd");
 }

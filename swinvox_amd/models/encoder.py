@@ -164,7 +164,7 @@ class Encoder(HipModule):
         side.wait_stream(main)                                             # fork: the Swin backbone runs beside the ResNet trunk
         ready = []
         with torch.cuda.stream(side):
-            feats, swin_tape = swin_forward(self.swin_transformer, img, I, tr, sto, seeds, ready)
+            feats, swin_tape = swin_forward(self.swin_transformer, img, I, tr, sto, seeds, ready, save)
         # ---- ResNet trunk
         x, g, c_stem = self._stem_fwd(images, I, tr)
         mp = empty(I * 56 * 56, 64, like=x)

@@ -139,24 +139,41 @@ def _drop_scale(I, p, seed, like):
     return sc
 
 
-def block_forward(blk: SwinBlock, x, I, training, stochastic, seeds):
-    """x [I*res*res, C] -> same shape; returns (out, ctx)."""
+def block_forward(blk: SwinBlock, x, I, training, stochastic, seeds, save=True):
+    """x [I*res*res, C] -> same shape; returns (out, ctx).  save=False (no backward will follow): the fused attention branch
+    skips the tensors it would store for the backward."""
     H = W = blk.res
     Cd, M = blk.dim, I * H * W
-    ln1, m1, r1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, M, Cd)
-    qkv = empty(M, 3 * Cd, like=x)
-    ops.linear_fwd(ln1, M, blk.s_qkv, blk.attn.qkv.weight, qkv, bias=blk.attn.qkv.bias)
-    att = empty(M, Cd, like=x)
-    # algorithmic work of the core (49-token windows, no padding): QK^T + PV = 4 * 49 * 32 flop per (token, head); bytes: qkv in, out
-    esz = 2.0 if x.dtype == torch.bfloat16 else 4.0
-    ops.traced_call("sv_window_attention_fwd", 4.0 * 49 * 32 * M * blk.heads, esz * 4 * M * Cd, ptr(qkv), ptr(blk.attn.relative_position_bias_table),
-                    ptr(att), I, H, W, Cd, blk.heads, blk.shift, ops.attention_math(), tag=f"M={M} C={Cd}")
     dp = blk.drop_path if (training and stochastic) else 0.0
-    sc1 = _drop_scale(I, dp, seeds(), x) if dp > 0 else None
-    sc2 = _drop_scale(I, dp, seeds(), x) if dp > 0 else None
-    x1 = empty(M, Cd, like=x)
-    ops.linear_fwd(att, M, blk.s_proj, blk.attn.proj.weight, x1, bias=blk.attn.proj.bias, residual=x, ldr=Cd, row_scale=sc1,
-                   rows_per_scale=H * W)
+    esz = 2.0 if x.dtype == torch.bfloat16 else 4.0
+    if ops.fused_attn_block_enabled(Cd, blk.heads):
+        # norm1 -> qkv -> window attention -> proj -> drop-path -> +x in ONE kernel; with save it also stores what the unfused backward reads
+        sc1 = _drop_scale(I, dp, seeds(), x) if dp > 0 else None
+        sc2 = _drop_scale(I, dp, seeds(), x) if dp > 0 else None
+        x1 = empty(M, Cd, like=x)
+        ln1 = qkv = att = m1 = r1 = None
+        if save:
+            ln1, qkv, att = empty(M, Cd, like=x), empty(M, 3 * Cd, like=x), empty(M, Cd, like=x)
+            m1, r1 = fempty(M, like=x), fempty(M, like=x)
+        a = blk.attn
+        # LayerNorm-free products of the branch: qkv + QK^T + PV + proj per token; bytes: x in, x1 out (+ the 5 saved rows when training)
+        ops.traced_call("sv_swin_attn_block_fwd", 2.0 * M * Cd * 4 * Cd + 4.0 * 49 * 32 * M * blk.heads, esz * M * Cd * (7 if save else 2),
+                        ptr(x), ptr(blk.norm1.weight), ptr(blk.norm1.bias), ptr(a.qkv.weight), ptr(a.qkv.bias), ptr(a.relative_position_bias_table),
+                        ptr(a.proj.weight), ptr(a.proj.bias), ptr(sc1), ptr(x1), ptr(ln1), ptr(m1), ptr(r1), ptr(qkv), ptr(att),
+                        I, H, W, Cd, blk.heads, blk.shift, float(blk.norm1.eps), tag=f"M={M} C={Cd}")
+    else:
+        ln1, m1, r1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, M, Cd)
+        qkv = empty(M, 3 * Cd, like=x)
+        ops.linear_fwd(ln1, M, blk.s_qkv, blk.attn.qkv.weight, qkv, bias=blk.attn.qkv.bias)
+        att = empty(M, Cd, like=x)
+        # algorithmic work of the core (49-token windows, no padding): QK^T + PV = 4 * 49 * 32 flop per (token, head); bytes: qkv in, out
+        ops.traced_call("sv_window_attention_fwd", 4.0 * 49 * 32 * M * blk.heads, esz * 4 * M * Cd, ptr(qkv), ptr(blk.attn.relative_position_bias_table),
+                        ptr(att), I, H, W, Cd, blk.heads, blk.shift, ops.attention_math(), tag=f"M={M} C={Cd}")
+        sc1 = _drop_scale(I, dp, seeds(), x) if dp > 0 else None
+        sc2 = _drop_scale(I, dp, seeds(), x) if dp > 0 else None
+        x1 = empty(M, Cd, like=x)
+        ops.linear_fwd(att, M, blk.s_proj, blk.attn.proj.weight, x1, bias=blk.attn.proj.bias, residual=x, ldr=Cd, row_scale=sc1,
+                       rows_per_scale=H * W)
     if ops.fused_mlp_enabled(Cd):
         # norm2 -> fc1 -> GELU -> fc2 -> drop-path -> +x1 in ONE kernel; the 4C-wide hidden activation never reaches HBM
         packs = torch.empty(16 * Cd * Cd, dtype=torch.bfloat16, device=x.device)
@@ -250,7 +267,7 @@ def _attention_backward(blk, x, m1, r1, ln1, qkv, att, sc1, dx1, grads, I, H, W,
     return dx1
 
 
-def swin_forward(st: SwinTransformer, img_nhwc, I, training, stochastic, seeds, ready=None):
+def swin_forward(st: SwinTransformer, img_nhwc, I, training, stochastic, seeds, ready=None, save=True):
     """img_nhwc [I,224,224,3] -> list of stage-head outputs [I*HW, C] (NHWC rows) + tape.  `ready` (optional list) receives
     one event per head output, recorded on the current stream as soon as that output is complete, so that another stream
     can consume the early stages while the later ones are still being computed."""
@@ -277,7 +294,7 @@ def swin_forward(st: SwinTransformer, img_nhwc, I, training, stochastic, seeds, 
             sctx["merge"] = (x, lnm, mm, rm, Mo, Hin)
             x = y
         for blk in stage.blocks:
-            x, bctx = block_forward(blk, x, I, training, stochastic, seeds)
+            x, bctx = block_forward(blk, x, I, training, stochastic, seeds, save)
             sctx["blocks"].append(bctx)
         tape["stages"].append(sctx)
         if si in bb.out_indices:

@@ -479,6 +479,21 @@ def fused_mlp_enabled(C: int) -> bool:
             and C <= lim and hip.load().sv_swin_mlp_supported(C) == 1)
 
 
+def fused_attn_block_enabled(C: int, heads: int) -> bool:
+    """The fused attention branch (LayerNorm -> qkv -> window attention -> proj -> residual, csrc/attn.hip) serves stage 0 of Swin-T
+    (C = 96, 3 heads) in bf16 MFMA + bf16 storage; fp8 attention keeps the unfused chain (its core kernel is a separate build)."""
+    import os
+    if os.environ.get("SV_FUSED_ATTN_BLOCK", "1") == "0" or not _STATE.get("fused_attn_block", True) or _STATE.get("attn_fp8"):
+        return False
+    return (_STATE["math"] == hip.MATH_BF16 and _STATE["store"] == torch.bfloat16
+            and hip.load().sv_swin_attn_block_supported(C, heads, hip.BF16, hip.MATH_BF16) == 1)
+
+
+def set_fused_attn_block(on: bool) -> None:
+    """A/B switch: False routes the attention branch of every Swin block through the unfused LayerNorm / qkv / core / proj chain."""
+    _STATE["fused_attn_block"] = bool(on)
+
+
 def set_attention_fp8(on: bool) -> None:
     """BASELINE configuration 5: QK^T and PV of the Swin window attention FORWARD on fp8 (OCP e4m3) MFMA operands with per-(window, head)
     scales; everything else (and the whole backward) keeps bf16 operands.  Needs set_math('bf16')."""

@@ -1,0 +1,139 @@
+"""Fused attention branch of a stage-0 Swin block (csrc/attn.hip: sv_swin_attn_block_fwd) against
+ (a) a plain PyTorch fp32 reference of x1 = x + s * proj(window_attention(qkv(LayerNorm(x)))) - timm SwinTransformerBlock._attn + the
+     residual / DropPath of its forward(), models/swin_transformer.py:78 - built from the oracle's index / mask helpers, and
+ (b) the unfused kernel chain (sv_layernorm_fwd -> engine linear -> sv_window_attention_fwd -> engine linear with the residual epilogue),
+     whose stored tensors (LayerNorm output + statistics, qkv, head outputs) the fused kernel reproduces as side outputs for the backward.
+Inputs are bf16-representable; the kernel rounds to bf16 exactly where the unfused chain stores, so (b) agrees to bf16 rounding of single
+elements and (a) to the bf16 tolerance of tests/test_gpu_bf16_storage.py."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from swinvox_amd import hip, ops  # noqa: E402
+from swinvox_amd.hip import call, ptr  # noqa: E402
+from swinvox_amd.ops import ConvSpec  # noqa: E402
+
+C, HEADS = 96, 3
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _case(I, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    M = I * H * H
+    p = {
+        "x": _bf(torch.randn(M, C, generator=g) * 1.5 + 0.2),
+        "lg": 1 + 0.1 * torch.randn(C, generator=g), "lb": 0.1 * torch.randn(C, generator=g),
+        "wqkv": torch.randn(3 * C, C, generator=g) / C ** 0.5, "bqkv": 0.1 * torch.randn(3 * C, generator=g),
+        "table": 0.5 * torch.randn(169, HEADS, generator=g),
+        "wproj": torch.randn(C, C, generator=g) / C ** 0.5, "bproj": 0.1 * torch.randn(C, generator=g),
+    }
+    return p
+
+
+def _reference(p, I, H, shift, sc):
+    from oracle.model import rel_pos_index, shift_attn_mask
+    x = p["x"].double()
+    ln = torch.nn.functional.layer_norm(x, (C,), p["lg"].double(), p["lb"].double(), 1e-5)
+    qkv = ln @ p["wqkv"].double().T + p["bqkv"].double()
+    t = qkv.view(I, H, H, 3 * C)
+    if shift:
+        t = torch.roll(t, (-shift, -shift), (1, 2))
+    tw = t.view(I, H // 7, 7, H // 7, 7, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 49, 3, HEADS, 32).permute(2, 0, 3, 1, 4)
+    q, k, v = tw[0] * 32 ** -0.5, tw[1], tw[2]
+    a = q @ k.transpose(-2, -1) + p["table"].double()[rel_pos_index(7).reshape(-1)].view(49, 49, HEADS).permute(2, 0, 1)[None]
+    if shift:
+        m = shift_attn_mask(H, H, 7, shift).double()
+        a = (a.view(I, -1, HEADS, 49, 49) + m[None, :, None]).view(-1, HEADS, 49, 49)
+    o = (a.softmax(-1) @ v).transpose(1, 2).reshape(-1, 49, C)
+    o = o.view(I, H // 7, H // 7, 7, 7, C).permute(0, 1, 3, 2, 4, 5).reshape(I, H, H, C)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    att = o.reshape(-1, C)
+    y = att @ p["wproj"].double().T + p["bproj"].double()
+    s = torch.ones(I, dtype=torch.float64) if sc is None else sc.double()
+    x1 = x + s.repeat_interleave(H * H)[:, None] * y
+    return {"x1": x1.float(), "ln1": ln.float(), "qkv": qkv.float(), "att": att.float()}
+
+
+def _fused(d, I, H, shift, scd, side):
+    dev = d["x"].device
+    M = I * H * H
+    b16 = dict(dtype=torch.bfloat16, device=dev)
+    x1 = torch.empty(M, C, **b16)
+    ln1 = qkv = att = m1 = r1 = None
+    if side:
+        ln1, qkv, att = torch.empty(M, C, **b16), torch.empty(M, 3 * C, **b16), torch.empty(M, C, **b16)
+        m1, r1 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    call("sv_swin_attn_block_fwd", ptr(d["x"]), ptr(d["lg"]), ptr(d["lb"]), ptr(d["wqkv"]), ptr(d["bqkv"]), ptr(d["table"]), ptr(d["wproj"]),
+         ptr(d["bproj"]), ptr(scd), ptr(x1), ptr(ln1), ptr(m1), ptr(r1), ptr(qkv), ptr(att), I, H, H, C, HEADS, shift, 1e-5, act=hip.BF16)
+    torch.cuda.synchronize()
+    return {"x1": x1, "ln1": ln1, "qkv": qkv, "att": att, "mean": m1, "rstd": r1}
+
+
+def _unfused(d, I, H, shift, scd):
+    """the kernel chain block_forward() runs when the fused kernel is switched off"""
+    M = I * H * H
+    x = d["x"]
+    ln1, m1, r1 = ops.layernorm_fwd(x, d["lg"], d["lb"], M, C)
+    s_qkv, s_proj = ConvSpec.linear(C, 3 * C), ConvSpec.linear(C, C)
+    qkv = ops.empty(M, 3 * C, like=x)
+    ops.linear_fwd(ln1, M, s_qkv, d["wqkv"], qkv, bias=d["bqkv"])
+    att = ops.empty(M, C, like=x)
+    call("sv_window_attention_fwd", ptr(qkv), ptr(d["table"]), ptr(att), I, H, H, C, HEADS, shift, hip.MATH_BF16)
+    x1 = ops.empty(M, C, like=x)
+    ops.linear_fwd(att, M, s_proj, d["wproj"], x1, bias=d["bproj"], residual=x, ldr=C, row_scale=scd, rows_per_scale=H * H)
+    torch.cuda.synchronize()
+    return {"x1": x1, "ln1": ln1, "qkv": qkv, "att": att, "mean": m1, "rstd": r1}
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("I,H,shift,with_scale", [(2, 14, 0, False), (3, 14, 3, True), (1, 28, 3, False), (5, 7, 0, True), (40, 14, 3, True)])
+def test_fused_attention_branch_matches_torch_and_the_unfused_chain(dev, I, H, shift, with_scale):
+    assert hip.load().sv_swin_attn_block_supported(C, HEADS, hip.BF16, hip.MATH_BF16) == 1
+    assert hip.load().sv_swin_attn_block_supported(192, 6, hip.BF16, hip.MATH_BF16) == 0
+    p = _case(I, H, 7 * I + H + shift)
+    sc = torch.tensor([0.0 if i % 3 == 1 else 1.0 / 0.9 for i in range(I)]) if with_scale else None
+    ref = _reference(p, I, H, shift, sc)
+    d = {k: (v.to(torch.bfloat16) if k == "x" else v).to(dev).contiguous() for k, v in p.items()}
+    scd = sc.to(dev) if sc is not None else None
+    got = _fused(d, I, H, shift, scd, side=True)
+    # (a) against fp32 torch: bf16 operands and bf16-stored intermediates
+    for k, tol in (("ln1", 1e-2), ("qkv", 1.5e-2), ("att", 2e-2), ("x1", 2e-2)):
+        assert _rel(got[k], ref[k]) < tol, (k, _rel(got[k], ref[k]))
+    # the inference form (no side outputs) is the same arithmetic
+    lean = _fused(d, I, H, shift, scd, side=False)
+    assert torch.equal(lean["x1"], got["x1"])
+    # (b) against the unfused chain in bf16 math + bf16 storage: every tensor the backward reads
+    ops.set_math("bf16")
+    ops.set_storage("bf16")
+    try:
+        un = _unfused(d, I, H, shift, scd)
+    finally:
+        ops.set_math("f32")
+    assert _rel(got["mean"], un["mean"]) < 1e-5 and _rel(got["rstd"], un["rstd"]) < 1e-5
+    for k, tol in (("ln1", 8e-3), ("qkv", 8e-3), ("att", 1.2e-2), ("x1", 1.2e-2)):     # a bf16 ulp of the largest element is 2^-8 = 3.9e-3
+        assert _rel(got[k], un[k]) < tol, (k, _rel(got[k], un[k]))
+        frac = float((got[k].float() != un[k].float()).float().mean())
+        assert frac < 0.2, (k, frac)               # differing summation order flips the rounding of a minority of the elements
+
+
+def test_fused_attention_branch_rejects_bad_arguments(dev):
+    z = torch.zeros(2 * 196, 96, dtype=torch.bfloat16, device=dev)
+    f = torch.zeros(3 * 96 * 96, device=dev)
+    args = [ptr(z), ptr(f), ptr(f), ptr(f), ptr(f), ptr(f), ptr(f), ptr(f), None, ptr(z)]
+    with pytest.raises(RuntimeError, match="swin_attn_block"):
+        call("sv_swin_attn_block_fwd", *args, None, None, None, None, None, 2, 14, 14, 192, 6, 0, 1e-5, act=hip.BF16)     # unsupported width
+    with pytest.raises(RuntimeError, match="swin_attn_block"):
+        call("sv_swin_attn_block_fwd", *args, ptr(z), None, None, None, None, 2, 14, 14, 96, 3, 0, 1e-5, act=hip.BF16)   # partial side outputs
+    with pytest.raises(RuntimeError, match="swin_attn_block"):
+        call("sv_swin_attn_block_fwd", *args, None, None, None, None, None, 2, 14, 14, 96, 3, 0, 1e-5, act=hip.F32)      # fp32 token rows
+    with pytest.raises(RuntimeError, match="swin_attn_block"):
+        call("sv_swin_attn_block_fwd", *args, None, None, None, None, None, 2, 15, 14, 96, 3, 0, 1e-5, act=hip.BF16)     # not a multiple of 7
