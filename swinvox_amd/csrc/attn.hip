@@ -1055,10 +1055,24 @@ struct BlockFwdArgs {
 };
 constexpr int FB_SMEM = (288 + 96) * FB_LDW * 2 + 2 * 64 * FB_LDT * 2 + (3 * 176 + 288 + 3 * 96) * 4;
 
+// all-reduce over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48) on the VALU: v_permlane16_swap exchanges the odd rows of one
+// operand with the even rows of the other, v_permlane32_swap the upper half with the lower half - with both operands the same register the
+// two results are "mine" and "the partner's" (no LDS crossbar round trip as ds_bpermute / __shfl_xor would take)
+// (inline asm: through __builtin_amdgcn_permlane16_swap hipcc 7.2 propagates the copy it made for the second operand across the
+// instruction - which rewrites BOTH registers - and adds the first result to itself; s_nop 1 covers the VALU-write -> permlane-read hazard
+// the compiler would have covered)
+template <typename OP> __device__ __forceinline__ float lanegroup_allreduce(float v, OP op) {
+  float w = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+  v = op(v, w); w = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+  return op(v, w);
+}
+
 __global__ __launch_bounds__(512, 1) void swin_attn_block_fwd_kernel(const BlockFwdArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char fb_smem[FB_SMEM];
-  __bf16* Wq = reinterpret_cast<__bf16*>(fb_smem);          // [288][FB_LDW]  qkv.weight rows (out, in)
-  __bf16* Wp = Wq + 288 * FB_LDW;                            // [96][FB_LDW]   proj.weight rows
+  __bf16* Wq = reinterpret_cast<__bf16*>(fb_smem);          // [288][FB_LDW]  qkv.weight rows (out, in), rows permuted inside 32-row chunks (below)
+  __bf16* Wp = Wq + 288 * FB_LDW;                            // [96][FB_LDW]   proj.weight rows, same permutation
   __bf16* Tb = Wp + 96 * FB_LDW;                             // 2 x [64][FB_LDT]  q (-> O) | k | v of the two windows in flight
   float* bt = reinterpret_cast<float*>(Tb + 2 * 64 * FB_LDT);   // [3][176] relative-position bias table per head, times log2 e
   float* bq = bt + 3 * 176;                                  // [288] qkv bias
@@ -1067,17 +1081,16 @@ __global__ __launch_bounds__(512, 1) void swin_attn_block_fwd_kernel(const Block
   float* lnb = lng + 96;                                     // [96] norm1 bias
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;
   const int lr = lane & 15, lg = lane >> 4;
-  for (int i = tid; i < 288 * 24; i += 512) {
-    const int n = i / 24, c4 = (i - n * 24) * 4;
-    const float4 w = ld4f(p.wqkv + n * FB_C + c4);
+  // A transposed 16 x 16 accumulator block leaves MFMA row i = 4 lg + j in register j of lane group lg.  Feeding the weight rows of a
+  // 32-column chunk in the order  block `half`, MFMA row i  <-  output column 8 (i >> 2) + 4 half + (i & 3)  makes the two blocks of a
+  // chunk hold the 8 CONSECUTIVE columns 8 lg .. 8 lg + 7 of a token in one lane: every global access of the kernel is a 16-byte vector
+  // in the layout of the LayerNorm loads (4 lanes = 64 contiguous bytes of a token row).  The permutation is applied once, here.
+  for (int i = tid; i < (288 + 96) * 24; i += 512) {
+    const int R = i / 24, c4 = (i - R * 24) * 4;            // LDS row R = 32 chunk + 16 half + i
+    const int ii = R & 15, n = (R & ~31) + 8 * (ii >> 2) + 4 * ((R >> 4) & 1) + (ii & 3);
+    const float4 w = ld4f(R < 288 ? p.wqkv + n * FB_C + c4 : p.wproj + (n - 288) * FB_C + c4);
     bf16x4 b; b[0] = (__bf16)w.x; b[1] = (__bf16)w.y; b[2] = (__bf16)w.z; b[3] = (__bf16)w.w;
-    *reinterpret_cast<bf16x4*>(Wq + n * FB_LDW + c4) = b;
-  }
-  for (int i = tid; i < 96 * 24; i += 512) {
-    const int n = i / 24, c4 = (i - n * 24) * 4;
-    const float4 w = ld4f(p.wproj + n * FB_C + c4);
-    bf16x4 b; b[0] = (__bf16)w.x; b[1] = (__bf16)w.y; b[2] = (__bf16)w.z; b[3] = (__bf16)w.w;
-    *reinterpret_cast<bf16x4*>(Wp + n * FB_LDW + c4) = b;
+    *reinterpret_cast<bf16x4*>(Wq + R * FB_LDW + c4) = b;    // Wp follows Wq
   }
   for (int i = tid; i < 3 * 169; i += 512) { const int h = i / 169, e = i - h * 169; bt[h * 176 + e] = p.table[e * FB_HEADS + h] * ATTN_LOG2E; }
   for (int i = tid; i < 288; i += 512) bq[i] = p.bqkv[i];
@@ -1105,23 +1118,35 @@ __global__ __launch_bounds__(512, 1) void swin_attn_block_fwd_kernel(const Block
   const long long task0 = ((long long)blockIdx.x * 2 + grp) * p.tasks_per_group;
   const float qscale = p.scale * ATTN_LOG2E;
   const bf16x8 zero8 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+  const auto fmax2 = [](float a, float b) { return fmaxf(a, b); };
+  const auto fadd2 = [](float a, float b) { return a + b; };
 
-  bf16x8 xr[3] = {zero8, zero8, zero8};
-  auto fetch = [&](long long task) {                  // this lane's three 16-byte chunks of its token row of window `task`
-    xr[0] = zero8; xr[1] = zero8; xr[2] = zero8;
-    if (task < p.ntasks && qok) {
-      const TokMap tmn = task_map(task, nW, nWx, p.H, p.W, p.shift);
-      const __bf16* src = p.x + (size_t)tmn.row(q) * FB_C + lg * 8;
-      xr[0] = *reinterpret_cast<const bf16x8*>(src); xr[1] = *reinterpret_cast<const bf16x8*>(src + 32); xr[2] = *reinterpret_cast<const bf16x8*>(src + 64);
+  // the windows of a group are consecutive: (image, window row, window column) advance by increments, one division at the start
+  TokMap tnext = task_map(task0 < p.ntasks ? task0 : 0, nW, nWx, p.H, p.W, p.shift);
+  const int qty = (qok ? q : 0) / 7, qtx = (qok ? q : 0) - qty * 7;       // this lane's token inside the window
+  auto token_row = [&](const TokMap& t) -> size_t {
+    int ys = t.wy * 7 + qty + t.shift; if (ys >= t.H) ys -= t.H;
+    int xs = t.wx * 7 + qtx + t.shift; if (xs >= t.W) xs -= t.W;
+    return ((size_t)t.img * t.H + ys) * t.W + xs;
+  };
+  bf16x8 xn[3] = {zero8, zero8, zero8};              // prefetched rows of the NEXT window
+  auto fetch = [&](bool in_range) {                   // this lane's three 16-byte chunks of its token row of window `tnext`
+    xn[0] = zero8; xn[1] = zero8; xn[2] = zero8;
+    if (in_range && qok) {
+      const __bf16* src = p.x + token_row(tnext) * FB_C + lg * 8;
+      xn[0] = *reinterpret_cast<const bf16x8*>(src); xn[1] = *reinterpret_cast<const bf16x8*>(src + 32); xn[2] = *reinterpret_cast<const bf16x8*>(src + 64);
     }
   };
-  fetch(task0);
+  fetch(task0 < p.ntasks);
   for (int tt = 0; tt < p.tasks_per_group; ++tt) {
     const long long task = task0 + tt;
     const bool live = task < p.ntasks;                                   // uniform over the 4 waves of a window
-    const TokMap tm = task_map(live ? task : 0, nW, nWx, p.H, p.W, p.shift);
+    const TokMap tm = tnext;
     const bool valid = live && qok;
-    const size_t row = (size_t)tm.row(qok ? q : 0);
+    const size_t row = token_row(tm);
+    const bf16x8 xr[3] = {xn[0], xn[1], xn[2]};                          // kept for the residual: the projection's columns come out in this layout
+    if (++tnext.wx == nWx) { tnext.wx = 0; if (++tnext.wy == p.H / 7) { tnext.wy = 0; ++tnext.img; } }
+    fetch(tt + 1 < p.tasks_per_group && task + 1 < p.ntasks);           // issued before any store of this window, lands during its GEMMs
     // ---- LayerNorm of the wave's 16 rows, on the operand layout
     bf16x8 xf[3];
     {
@@ -1131,15 +1156,13 @@ __global__ __launch_bounds__(512, 1) void swin_attn_block_fwd_kernel(const Block
       for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { xv[ks][e] = (float)xr[ks][e]; s += xv[ks][e]; }
-      s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-      const float mean = s * (1.f / FB_C);
+      const float mean = lanegroup_allreduce(s, fadd2) * (1.f / FB_C);
       float v2 = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float a = xv[ks][e] - mean; v2 += a * a; }
-      v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
-      const float rstd = rsqrtf(v2 * (1.f / FB_C) + p.eps);
+      const float rstd = rsqrtf(lanegroup_allreduce(v2, fadd2) * (1.f / FB_C) + p.eps);
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
         const float4 g0 = *reinterpret_cast<const float4*>(lng + ks * 32 + lg * 8), g1 = *reinterpret_cast<const float4*>(lng + ks * 32 + lg * 8 + 4);
@@ -1154,32 +1177,35 @@ __global__ __launch_bounds__(512, 1) void swin_attn_block_fwd_kernel(const Block
         if (lg == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
       }
     }
-    fetch(tt + 1 < p.tasks_per_group ? task + 1 : (long long)p.ntasks);   // lands during the GEMMs below
-    // ---- qkv = LN(x) W^T + b as transposed blocks: lane -> token lr, output columns nb*16 + lg*4 .. +3
-#pragma unroll 2
-    for (int nb = 0; nb < 18; ++nb) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // ---- qkv = LN(x) W^T + b, one 32-column chunk (= one head of q, k or v) at a time: lane -> token lr, columns 32 ck + 8 lg .. + 7
+#pragma unroll 3
+    for (int ck = 0; ck < 9; ++ck) {
+      f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Wq + (nb * 16 + lr) * FB_LDW + ks * 32 + lg * 8);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xf[ks], acc, 0, 0, 0);
+      for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(Wq + (ck * 32 + hf * 16 + lr) * FB_LDW + ks * 32 + lg * 8);
+          acc[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xf[ks], acc[hf], 0, 0, 0);
+        }
+      const int n0 = ck * 32 + lg * 8;
+      const float4 b0 = *reinterpret_cast<const float4*>(bq + n0), b1 = *reinterpret_cast<const float4*>(bq + n0 + 4);
+      bf16x8 o;
+      o[0] = (__bf16)(acc[0][0] + b0.x); o[1] = (__bf16)(acc[0][1] + b0.y); o[2] = (__bf16)(acc[0][2] + b0.z); o[3] = (__bf16)(acc[0][3] + b0.w);
+      o[4] = (__bf16)(acc[1][0] + b1.x); o[5] = (__bf16)(acc[1][1] + b1.y); o[6] = (__bf16)(acc[1][2] + b1.z); o[7] = (__bf16)(acc[1][3] + b1.w);
+      if (valid && p.qkv) *reinterpret_cast<bf16x8*>(p.qkv + row * (3 * FB_C) + n0) = o;
+      if (ck < 3) {   // q: the softmax scale (and log2 e) goes onto the bf16 value, as the core kernel applies it to the q it reads from HBM
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] * qscale);
       }
-      const int n0 = nb * 16 + lg * 4;
-      const float4 bb = *reinterpret_cast<const float4*>(bq + n0);
-      bf16x4 o;
-      o[0] = (__bf16)(acc[0] + bb.x); o[1] = (__bf16)(acc[1] + bb.y); o[2] = (__bf16)(acc[2] + bb.z); o[3] = (__bf16)(acc[3] + bb.w);
-      if (valid && p.qkv) *reinterpret_cast<bf16x4*>(p.qkv + row * (3 * FB_C) + n0) = o;
-      if (nb < 6) {   // q: the softmax scale (and log2 e) goes onto the bf16 value, as the core kernel applies it to the q it reads from HBM
-        o[0] = (__bf16)((float)o[0] * qscale); o[1] = (__bf16)((float)o[1] * qscale); o[2] = (__bf16)((float)o[2] * qscale); o[3] = (__bf16)((float)o[3] * qscale);
-      }
-      *reinterpret_cast<bf16x4*>(T + q * FB_LDT + n0) = o;
+      *reinterpret_cast<bf16x8*>(T + q * FB_LDT + n0) = o;
     }
     __syncthreads();                                                     // all key / value rows of both windows are in LDS
     // ---- attention, one head at a time; lane -> query lr, keys nt*16 + lg*4 + j
     const bool masked = p.shift > 0 && (tm.wy == p.H / 7 - 1 || tm.wx == nWx - 1);
-    int qreg = 0; unsigned kdiff = 0;                                    // bit (nt*4 + j): key in another region than the query
+    unsigned kdiff = 0;                                                  // bit (nt*4 + j): key in another region than the query
     if (masked) {
-      qreg = qok ? tm.region(q) : 0;
+      const int qreg = qok ? tm.region(q) : 0;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -1204,19 +1230,27 @@ __global__ __launch_bounds__(512, 1) void swin_attn_block_fwd_kernel(const Block
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float v = bias[h][nt][j] <= -1.0e29f ? -1.0e30f : s[nt][j] + bias[h][nt][j];
-          if (kdiff & (1u << (nt * 4 + j))) v += -100.0f * ATTN_LOG2E;
+          const float v = s[nt][j] + bias[h][nt][j];      // key padding: bias = -1e30 and the padded K rows are finite (LayerNorm of a zero row = beta)
           s[nt][j] = v;
           mx = fmaxf(mx, v);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (masked) {                                        // uniform over the window: only the last window row / column of a shifted block
+        mx = -3.0e38f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (kdiff & (1u << (nt * 4 + j))) s[nt][j] += -100.0f * ATTN_LOG2E;
+            mx = fmaxf(mx, s[nt][j]);
+          }
+      }
+      mx = lanegroup_allreduce(mx, fmax2);
       float sum = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(s[nt][j] - mx); s[nt][j] = e; sum += e; }
-      sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
-      const float inv = __builtin_amdgcn_rcpf(sum);
+      const float inv = __builtin_amdgcn_rcpf(lanegroup_allreduce(sum, fadd2));
       bf16x8 pf[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -1227,42 +1261,46 @@ __global__ __launch_bounds__(512, 1) void swin_attn_block_fwd_kernel(const Block
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          // V^T fragment: head channel nt*16 + lr, the 8 keys of this lane group in the order the P fragment holds them
-          const __bf16* src = T + (2 * ks * 16 + lg * 4 + (lr >> 2)) * FB_LDT + 2 * FB_C + h * HD + nt * 16 + (lr & 3) * 4;
+          // V^T fragment of block nt: MFMA row lr <- head channel 8 (lr >> 2) + 4 nt + (lr & 3) (the chunk permutation above: the lanes with
+          // lr & 3 = c supply the 4-column group that the lanes with lr >> 2 = c receive), the 8 keys of this lane group in the order the P
+          // fragment holds them: keys 32 ks + 4 lg .. + 3 and 32 ks + 16 + 4 lg .. + 3
+          const __bf16* src = T + (2 * ks * 16 + lg * 4 + (lr >> 2)) * FB_LDT + 2 * FB_C + h * HD + (lr & 3) * 8 + nt * 4;
           const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src));
           const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src + 16 * FB_LDT));
           const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ks], o[nt], 0, 0, 0);
         }
+      bf16x8 ob;                                                         // lane -> query lr, head channels 8 lg .. 8 lg + 7
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {                                   // lane -> query lr, head channels nt*16 + lg*4 .. +3
-        bf16x4 ob;
-        ob[0] = (__bf16)o[nt][0]; ob[1] = (__bf16)o[nt][1]; ob[2] = (__bf16)o[nt][2]; ob[3] = (__bf16)o[nt][3];
-        if (valid && p.att) *reinterpret_cast<bf16x4*>(p.att + row * FB_C + h * HD + nt * 16 + lg * 4) = ob;
-        *reinterpret_cast<bf16x4*>(T + q * FB_LDT + h * HD + nt * 16 + lg * 4) = ob;   // over this wave's own q rows
-      }
+      for (int j = 0; j < 4; ++j) { ob[j] = (__bf16)o[0][j]; ob[4 + j] = (__bf16)o[1][j]; }
+      if (valid && p.att) *reinterpret_cast<bf16x8*>(p.att + row * FB_C + h * HD + lg * 8) = ob;
+      *reinterpret_cast<bf16x8*>(T + q * FB_LDT + h * HD + lg * 8) = ob;   // over this wave's own q rows
     }
     __syncthreads();                                                     // keys / values are consumed: the next window may overwrite them
-    // ---- x1 = x + s * (O Wp^T + bp), lane -> token lr, channels nb*16 + lg*4 .. +3
+    // ---- x1 = x + s * (O Wp^T + bp), lane -> token lr, channels 32 ck + 8 lg .. + 7: the layout x was loaded in
     {
       const float sc = p.row_scale ? p.row_scale[tm.img] : 1.f;
       bf16x8 of[3];
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) of[ks] = *reinterpret_cast<const bf16x8*>(T + q * FB_LDT + ks * 32 + lg * 8);
 #pragma unroll
-      for (int nb = 0; nb < 6; ++nb) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int ck = 0; ck < 3; ++ck) {
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(Wp + (nb * 16 + lr) * FB_LDW + ks * 32 + lg * 8);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, of[ks], acc, 0, 0, 0);
-        }
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(Wp + (ck * 32 + hf * 16 + lr) * FB_LDW + ks * 32 + lg * 8);
+            acc[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, of[ks], acc[hf], 0, 0, 0);
+          }
         if (valid) {
-          const int n0 = nb * 16 + lg * 4;
-          const float4 bb = *reinterpret_cast<const float4*>(bp + n0);
-          const float4 xres = ld4f(p.x + row * FB_C + n0);
-          st4f(p.x1 + row * FB_C + n0, make_float4(xres.x + sc * (acc[0] + bb.x), xres.y + sc * (acc[1] + bb.y),
-                                                    xres.z + sc * (acc[2] + bb.z), xres.w + sc * (acc[3] + bb.w)));
+          const int n0 = ck * 32 + lg * 8;
+          const float4 b0 = *reinterpret_cast<const float4*>(bp + n0), b1 = *reinterpret_cast<const float4*>(bp + n0 + 4);
+          const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+          bf16x8 y;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = (__bf16)((float)xr[ck][e] + sc * (acc[e >> 2][e & 3] + bb[e]));
+          *reinterpret_cast<bf16x8*>(p.x1 + row * FB_C + n0) = y;
         }
       }
     }
