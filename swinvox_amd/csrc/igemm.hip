@@ -639,6 +639,7 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR >= 512 ? 4 : 2) void gemm_dense_
 // Host-side conditions: K % 64 == 0, K >= 192, 8-aligned rows and columns (gemm_wide_ok).
 // ------------------------------------------------------------------------------------------------
 constexpr int GW_BN = 128, GW_BK = 64;
+constexpr unsigned GW_NODRAW = 0xFFFFFFFFu;   // content of the tile-draw register (v167) while the atomic's return is outstanding
 template <int CTRL> __device__ __forceinline__ float gw_dpp_add(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
@@ -737,14 +738,23 @@ __global__ __launch_bounds__((2 * WM + NPROD) * 64, 3) void gemm_wide_kernel(con
     bool have = true;
     while (have) {
       bool more = true;                                   // known from the second slice on (nk >= 3: the last slice is a later one)
-      unsigned drawn = 0;
       for (int kt = 0; kt < nk; ++kt) {
         // this wave's pieces of the slice have landed (ring of 3: the 12 of the next slice may stay in flight); behind the barrier every
         // producer's have, and every consumer is done reading the previous slice, whose ring slot the next issue overwrites
-        if (NST == 3 && (kt + 1 < nk || more)) asm volatile("s_waitcnt vmcnt(12)" : "+v"(drawn) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn) :: "memory");
-        if (kt == 1 && pw == 0 && lane == 0) {            // the draw of slice 0 is older than the 12 pieces waited past: it has returned
-          const int v = (int)drawn;
+        if (NST == 3 && (kt + 1 < nk || more)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt == 1 && pw == 0 && lane == 0) {            // the draw of slice 0 is older than the 12 pieces waited past: normally it has returned
+          // The atomic's return lands in a FIXED register, v167 (the kernel's budget at 3 waves per SIMD is 168 and the producer path needs
+          // far fewer; build/igemm.s shows no other use): a C++ variable tied to the asm statements can be copied by the register
+          // allocator between the issue and this read - seen in an experimental gathering variant of this kernel: a loop-carried copy
+          // taken right after the issue kept the old value, the return landed in a dead register, and a tile was computed twice
+          // (harmless for the output, fatal for the BatchNorm statistics).  The register holds GW_NODRAW until the return arrives - LDS-DMA
+          // pieces and an atomic's return take different paths back and need not retire in issue order - in which case the queue is
+          // drained once.
+          unsigned dv;
+          asm volatile("v_mov_b32 %0, v167" : "=v"(dv) :: "memory");
+          if (dv == GW_NODRAW) asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v167" : "=v"(dv) :: "memory");
+          const int v = (int)dv;
           mbox[(it + 1) & 1] = v < csize ? cbase + v : -1;
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -754,7 +764,7 @@ __global__ __launch_bounds__((2 * WM + NPROD) * 64, 3) void gemm_wide_kernel(con
           row0n = (tnext / tiles_n) * GW_BM; col0n = (tnext % tiles_n) * GW_BN;
         }
         if (kt == 0 && pw == 0 && lane == 0)              // draw the next tile: an atomic hipcc does not count (it would drain the DMA queue for it)
-          asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(ctr + xcd), "v"(1u) : "memory");
+          asm volatile("v_mov_b32 v167, -1\n\tglobal_atomic_add v167, %0, %1, off sc0" :: "v"(ctr + xcd), "v"(1u) : "memory", "v167");
         const int st2 = st == 0 ? NST - 1 : st - 1;       // = (st + LEAD) mod NST: the slot consumed a slice ago
         if (kt + LEAD < nk) issue(kt + LEAD, st2);
         else if (more) {

@@ -221,6 +221,46 @@ def test_conv2d_fwd_dgrad_wgrad(dev, cin, cout, k, s, p, H):
     assert rel(dw, w.grad) < TOL
 
 
+@pytest.mark.parametrize("cin,cout,k,s,p,H,relu", [(64, 64, 3, 1, 1, 183, False), (128, 136, 3, 2, 1, 270, True), (256, 264, 1, 2, 0, 230, False)])
+def test_conv2d_bf16_storage_large_maps(dev, cin, cout, k, s, p, H, relu):
+    """Forward convolutions at the row counts of the bench shapes (tens of thousands of rows, hundreds of tiles, a ragged last tile) in
+    bf16 storage: 3x3 / stride 1 and 2 and a strided 1x1 with bias (+ ReLU) and the BatchNorm statistics epilogue, against torch fp32 on
+    bf16-representable operands.  The statistics must equal the column sums of the STORED output exactly up to summation order - a tile
+    computed twice would leave the output intact and show up here."""
+    g = torch.Generator().manual_seed(cin + cout + H)
+    n = 2
+    x = torch.randn(n, cin, H, H, generator=g).bfloat16().float()
+    w = (torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).bfloat16().float()
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, w, b, stride=s, padding=p)
+    if relu:
+        ref = ref.relu()
+    ref = cl(ref)
+    sp = ConvSpec.conv2d(cin, cout, k, s, p)
+    og = sp.out_grid((1, H, H))
+    M = n * og[1] * og[2]
+    assert M % 256 != 0
+    ref = ref.reshape(M, cout)
+    ops.set_math("bf16")
+    ops.set_storage("bf16")
+    try:
+        xd = cl(x).to(dev).bfloat16()
+        wp = sp.pack_fwd(w.to(dev))
+        for _ in range(2):
+            out = ops.empty(M, cout, device=dev)
+            stats = torch.zeros(ops.BN_SLOTS, 2 * cout, dtype=torch.float64, device=dev)
+            epi = dict(bias=b.to(dev), stats=stats)
+            if relu:
+                epi["act"] = ACT_RELU
+            sp.forward(xd, n, (1, H, H), wp, out, **epi)
+            torch.cuda.synchronize()
+            assert rel(out.float(), ref) < 6e-3            # bf16 rounding of the stored output
+            st, o = stats.sum(0), out.float().cpu().double()
+            assert rel(st[:cout], o.sum(0)) < 1e-4 and rel(st[cout:], (o * o).sum(0)) < 1e-4      # fp32 partial sums per tile; one tile twice = 2e-3
+    finally:
+        ops.set_math("f32")
+
+
 CONV3D = [  # cin, cout, k, s, p, transposed, D
     (1, 32, 4, 1, 2, False, 8), (32, 64, 4, 1, 2, False, 8), (128, 64, 4, 2, 1, True, 4), (32, 8, 4, 2, 1, True, 8),
     (256, 128, (6, 4, 4), 2, (2, 1, 1), True, 2), (32, 1, 4, 2, 1, True, 8)]
