@@ -58,6 +58,20 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
+// all-reduce over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48) on the VALU: v_permlane16_swap exchanges the odd rows of one
+// operand with the even rows of the other, v_permlane32_swap the upper half with the lower half - with both operands the same register the
+// two results are "mine" and "the partner's" (no LDS crossbar round trip as ds_bpermute / __shfl_xor would take)
+// (inline asm: through __builtin_amdgcn_permlane16_swap hipcc 7.2 propagates the copy it made for the second operand across the
+// instruction - which rewrites BOTH registers - and adds the first result to itself; s_nop 1 covers the VALU-write -> permlane-read hazard
+// the compiler would have covered)
+template <typename OP> __device__ __forceinline__ float lanegroup_allreduce(float v, OP op) {
+  float w = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+  v = op(v, w); w = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+  return op(v, w);
+}
+
 // scores (+bias, +mask, key padding) -> softmax, all on the 4x4 grid of 16x16 accumulator tiles of one wave.
 // element (q = mt*16 + lg*4 + j, key = nt*16 + lr)
 __device__ __forceinline__ void bias_mask_softmax(f32x4 (&s)[4][4], const float* bt, const TokMap& tm, int lane, bool shifted) {
@@ -672,7 +686,12 @@ static inline unsigned wg_grid(int nchunks, int heads) { return 8u * (unsigned)h
 
 template <typename AT>
 __global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<AT> p) {
-  __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * LDQ_H], Ks[64 * LDQ_H], Vt[HD * LDP_H], Ps[64 * LDP_H];
+  // q (scaled) | k | v of the window's head, row-major [token][32 (+8)] bf16.  The products are taken with swapped operands (keys / V^T as
+  // the first MFMA operand): S^T = K Q^T leaves the 16 keys (16 nt + 4 lg + j) of query lr in one lane, so the softmax of a query is 16
+  // in-lane values + two lane-group exchanges, and the probabilities go into P V from the registers they are in (the contraction index of
+  // an MFMA may be permuted freely as long as both operands agree: the V^T fragment is fetched with ds_read_b64_tr_b16 from exactly those
+  // key rows) - no P tile, no transposed V copy, one barrier less per window than the first version of this kernel.
+  __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * LDQ_H], Ks[64 * LDQ_H], Vs[64 * LDQ_H];
   __shared__ float bt[176];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
@@ -680,12 +699,24 @@ __global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<
   if (!wg_chunk_head((p.ntasks + p.tasks_per_wave - 1) / p.tasks_per_wave, p.heads, chunk, head)) return;   // uniform over the workgroup
   const int nWx = p.W / 7, nW = (p.H / 7) * nWx;
   const int ld = 3 * p.C, colq = head * HD;
-  for (int i = tid; i < 169; i += 256) bt[i] = p.table[i * p.heads + head];
-  for (int i = tid; i < HD * LDP_H; i += 256) Vt[i] = (__bf16)0.f;      // key columns >= 49 stay zero
+  for (int i = tid; i < 169; i += 256) bt[i] = p.table[i * p.heads + head] * ATTN_LOG2E;
   __syncthreads();
-  float bias[4][4];
-  strip_bias(bias, bt, lane, wave, ATTN_LOG2E);
+  const int q = wave * 16 + lr;                      // the query of this lane
+  const bool qok = q < WT;
+  float bias[4][4];                                  // relative-position bias of this lane's 16 (query, key) slots: the same for every window
+  {
+    const int qy = q / 7, qx = q - qy * 7;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = nt * 16 + lg * 4 + j, ky = key / 7, kx = key - ky * 7;
+        bias[nt][j] = key >= WT ? -1.0e30f : (qok ? bt[(qy - ky + 6) * 13 + (qx - kx + 6)] : 0.f);   // key padding: excluded
+      }
+  }
   const float qscale = p.scale * ATTN_LOG2E;      // scores come out of the MFMA in log2 units
+  const auto fmax2 = [](float a, float b) { return fmaxf(a, b); };
+  const auto fadd2 = [](float a, float b) { return a + b; };
   const long long task0 = (long long)chunk * p.tasks_per_wave;
   for (int tt = 0; tt < p.tasks_per_wave; ++tt) {
     const long long task = task0 + tt;
@@ -695,54 +726,75 @@ __global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int r = (tid >> 3) + 32 * it, ch = (tid & 7) * 4;
-      float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;
+      float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;   // rows >= 49: zeros (finite values under zero probabilities)
       if (r < WT) {
         const AT* src = p.qkv + (size_t)tm.row(r) * ld + colq + ch;
         q4 = ld4f(src); k4 = ld4f(src + p.C); v4 = ld4f(src + 2 * p.C);
       }
-      bf16x4 qb, kb;
+      bf16x4 qb, kb, vb;
       qb[0] = (__bf16)(q4.x * qscale); qb[1] = (__bf16)(q4.y * qscale); qb[2] = (__bf16)(q4.z * qscale); qb[3] = (__bf16)(q4.w * qscale);
       kb[0] = (__bf16)k4.x; kb[1] = (__bf16)k4.y; kb[2] = (__bf16)k4.z; kb[3] = (__bf16)k4.w;
+      vb[0] = (__bf16)v4.x; vb[1] = (__bf16)v4.y; vb[2] = (__bf16)v4.z; vb[3] = (__bf16)v4.w;
       *reinterpret_cast<bf16x4*>(Qs + r * LDQ_H + ch) = qb;
       *reinterpret_cast<bf16x4*>(Ks + r * LDQ_H + ch) = kb;
-      if (r < WT) {
-        Vt[(ch + 0) * LDP_H + r] = (__bf16)v4.x; Vt[(ch + 1) * LDP_H + r] = (__bf16)v4.y;
-        Vt[(ch + 2) * LDP_H + r] = (__bf16)v4.z; Vt[(ch + 3) * LDP_H + r] = (__bf16)v4.w;
-      }
+      *reinterpret_cast<bf16x4*>(Vs + r * LDQ_H + ch) = vb;
     }
     __syncthreads();
     f32x4 s[4];
     {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + (wave * 16 + lr) * LDQ_H + lg * 8);
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + q * LDQ_H + lg * 8);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Ks + (nt * 16 + lr) * LDQ_H + lg * 8);
-        s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (nt * 16 + lr) * LDQ_H + lg * 8);
+        s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // lane: query lr, keys 16 nt + 4 lg + j
       }
     }
-    bias_mask_softmax_strip<true>(s, bias, tm, lane, p.shift > 0 && (tm.wy == p.H / 7 - 1 || tm.wx == nWx - 1), wave);
+    float mx = -3.0e38f;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Ps[(wave * 16 + lg * 4 + j) * LDP_H + nt * 16 + lr] = (__bf16)s[nt][j];
-    __syncthreads();
+      for (int j = 0; j < 4; ++j) { s[nt][j] += bias[nt][j]; mx = fmaxf(mx, s[nt][j]); }
+    if (p.shift > 0 && (tm.wy == p.H / 7 - 1 || tm.wx == nWx - 1)) {    // a window touching the rolled seam: regions must not attend to each other
+      const int qreg = qok ? tm.region(q) : 0;
+      mx = -3.0e38f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = nt * 16 + lg * 4 + j;
+          if (qok && key < WT && tm.region(key) != qreg) s[nt][j] += -100.0f * ATTN_LOG2E;
+          mx = fmaxf(mx, s[nt][j]);
+        }
+    }
+    mx = lanegroup_allreduce(mx, fmax2);
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(s[nt][j] - mx); s[nt][j] = e; sum += e; }
+    const float inv = __builtin_amdgcn_rcpf(lanegroup_allreduce(sum, fadd2));   // 1 ulp: the quotient is rounded to bf16 right after
+    bf16x8 pf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { pf[ks][j] = (__bf16)(s[2 * ks][j] * inv); pf[ks][4 + j] = (__bf16)(s[2 * ks + 1][j] * inv); }
     f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ps + (wave * 16 + lr) * LDP_H + ks * 32 + lg * 8);
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Vt + (nt * 16 + lr) * LDP_H + ks * 32 + lg * 8);
-        o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, o[nt], 0, 0, 0);   // operands swapped: the accumulator is the
-      }                                                                              // transposed block, O[q = lr][d = lg*4 + j]
-    }
-    {   // four consecutive channels per lane: one vector store per 16-column block instead of four 2-byte scatters
-      const int q = wave * 16 + lr;
-      if (q < WT) {
-        AT* dst = p.out + (size_t)tm.row(q) * p.C + colq + lg * 4;
-        st4f(dst, make_float4(o[0][0], o[0][1], o[0][2], o[0][3]));
-        st4f(dst + 16, make_float4(o[1][0], o[1][1], o[1][2], o[1][3]));
+        // V^T fragment of block nt: MFMA row lr <- head channel 8 (lr >> 2) + 4 nt + (lr & 3) (the lanes with lr & 3 = c supply the 4-column
+        // group that the lanes with lr >> 2 = c receive), keys 32 ks + 4 lg .. + 3 and 32 ks + 16 + 4 lg .. + 3: the order of the P fragment
+        const __bf16* src = Vs + (2 * ks * 16 + lg * 4 + (lr >> 2)) * LDQ_H + (lr & 3) * 8 + nt * 4;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src + 16 * LDQ_H));
+        const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ks], o[nt], 0, 0, 0);
       }
+    if (qok) {   // lane: query lr, head channels 8 lg .. 8 lg + 7 (block nt holds 8 lg + 4 nt + j): one 16-byte vector of bf16 rows
+      AT* dst = p.out + (size_t)tm.row(q) * p.C + colq + lg * 8;
+      st4f(dst, make_float4(o[0][0], o[0][1], o[0][2], o[0][3]));
+      st4f(dst + 4, make_float4(o[1][0], o[1][1], o[1][2], o[1][3]));
     }
   }
 }
@@ -1054,20 +1106,6 @@ struct BlockFwdArgs {
   int I, H, W, shift; float eps, scale; int ntasks, tasks_per_group;
 };
 constexpr int FB_SMEM = (288 + 96) * FB_LDW * 2 + 2 * 64 * FB_LDT * 2 + (3 * 176 + 288 + 3 * 96) * 4;
-
-// all-reduce over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48) on the VALU: v_permlane16_swap exchanges the odd rows of one
-// operand with the even rows of the other, v_permlane32_swap the upper half with the lower half - with both operands the same register the
-// two results are "mine" and "the partner's" (no LDS crossbar round trip as ds_bpermute / __shfl_xor would take)
-// (inline asm: through __builtin_amdgcn_permlane16_swap hipcc 7.2 propagates the copy it made for the second operand across the
-// instruction - which rewrites BOTH registers - and adds the first result to itself; s_nop 1 covers the VALU-write -> permlane-read hazard
-// the compiler would have covered)
-template <typename OP> __device__ __forceinline__ float lanegroup_allreduce(float v, OP op) {
-  float w = v;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(w));
-  v = op(v, w); w = v;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v), "+v"(w));
-  return op(v, w);
-}
 
 __global__ __launch_bounds__(512, 1) void swin_attn_block_fwd_kernel(const BlockFwdArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char fb_smem[FB_SMEM];
