@@ -925,8 +925,25 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
   const int ld = 3 * p.C, colq = head * HD;
   for (int i = tid; i < 176; i += 256) { bt[i] = i < 169 ? p.table[i * p.heads + head] : 0.f; dbt[i] = 0.f; }
   __syncthreads();
+  // Score blocks are taken transposed (keys as the first MFMA operand): lane -> query 16 wave + lr, keys 16 nt + 4 lg + j.  The softmax and
+  // the row sum of dP o P of a query are then 16 in-lane values + two lane-group exchanges (the first version reduced every accumulator
+  // row over 16 lanes), P and dS reach their LDS tiles as 8-byte row vectors instead of 2-byte scatters, and dQ = dS K takes dS from the
+  // registers it is in (K^T fragments by ds_read_b64_tr_b16 in the key order of those registers, as the forward kernel does with V).
+  const int qrow = wave * 16 + lr;
+  const bool qrow_ok = qrow < WT;
   float bias[4][4];
-  strip_bias(bias, bt, lane, wave);
+  {
+    const int qy = qrow / 7, qx = qrow - qy * 7;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = nt * 16 + lg * 4 + j, ky = key / 7, kx = key - ky * 7;
+        bias[nt][j] = key >= WT ? -1.0e30f : (qrow_ok ? bt[(qy - ky + 6) * 13 + (qx - kx + 6)] : 0.f);   // key padding: excluded
+      }
+  }
+  const auto fmax2 = [](float a, float b) { return fmaxf(a, b); };
+  const auto fadd2 = [](float a, float b) { return a + b; };
   f32x4 dsum[4];                                   // sum over this workgroup's windows of dS at this lane's (query, key) slots
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) dsum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -970,73 +987,119 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
     for (int it = 0; it < 2; ++it) { put(Qs, rq[it], it, p.scale); put(Ks, rk[it], it, 1.f); put(Vs, rv[it], it, 1.f); put(Ds, rd[it], it, 1.f); }
     __syncthreads();
     if (tt + 1 < p.tasks_per_wave && task + 1 < p.ntasks) fetch(task + 1);
-    // ---- this wave's 16 query rows: S = (scale Q) K^T, dP = dO V^T, P = softmax, dS = P o (dP - rowsum(dP o P))
+    // ---- this wave's 16 queries: S^T = K (scale Q)^T, dP^T = V dO^T, P = softmax, dS = P o (dP - rowsum(dP o P))
     f32x4 s[4], dp[4];
     {
-      const int off = (wave * 16 + lr) * LDQ_H + lg * 8;
+      const int off = qrow * LDQ_H + lg * 8;
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + off), c = *reinterpret_cast<const bf16x8*>(Ds + off);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const int offb = (nt * 16 + lr) * LDQ_H + lg * 8;
         const bf16x8 b = *reinterpret_cast<const bf16x8*>(Ks + offb), d = *reinterpret_cast<const bf16x8*>(Vs + offb);
-        s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, d, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d, c, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       }
     }
 #ifndef SV_AT_PROBE_NOSOFTMAX
-    bias_mask_softmax_strip(s, bias, tm, lane, p.shift > 0 && (tm.wy == p.H / 7 - 1 || tm.wx == nWx - 1), wave);
-#endif
+    {
+      float mx = -3.0e38f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[nt][j] += bias[nt][j]; mx = fmaxf(mx, s[nt][j]); }
+      if (p.shift > 0 && (tm.wy == p.H / 7 - 1 || tm.wx == nWx - 1)) {    // a window touching the rolled seam
+        const int qreg = qrow_ok ? tm.region(qrow) : 0;
+        mx = -3.0e38f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int key = nt * 16 + lg * 4 + j;
+            if (qrow_ok && key < WT && tm.region(key) != qreg) s[nt][j] += -100.0f;
+            mx = fmaxf(mx, s[nt][j]);
+          }
+      }
+      mx = lanegroup_allreduce(mx, fmax2);
+      float sum = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float e = __expf(s[nt][j] - mx); s[nt][j] = e; sum += e; }
+      const float inv = __builtin_amdgcn_rcpf(lanegroup_allreduce(sum, fadd2));
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[nt][j] *= inv;
+    }
+#endif
+    {
       float r = 0.f;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) r += dp[nt][j] * s[nt][j];
-      r = group16_sum(r);
-      const bool qok = wave * 16 + lg * 4 + j < WT;
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const float dsv = s[nt][j] * (dp[nt][j] - r);
-        dp[nt][j] = dsv;
-        if (qok && nt * 16 + lr < WT) dsum[nt][j] += dsv;
-      }
+        for (int j = 0; j < 4; ++j) r += dp[nt][j] * s[nt][j];
+      r = lanegroup_allreduce(r, fadd2);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float dsv = s[nt][j] * (dp[nt][j] - r);
+          dp[nt][j] = dsv;
+          if (qrow_ok && nt * 16 + lg * 4 + j < WT) dsum[nt][j] += dsv;
+        }
     }
+    bf16x8 dsf[2];                                   // dS of this query as the second operand of dQ = dS K: keys 32 ks + 4 lg .. + 3, 32 ks + 16 + 4 lg .. + 3
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < 4; ++nt) {
+      bf16x4 pb, sb;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int o = (wave * 16 + lg * 4 + j) * LDP_H + nt * 16 + lr;
+      for (int j = 0; j < 4; ++j) { pb[j] = (__bf16)s[nt][j]; sb[j] = (__bf16)dp[nt][j]; dsf[nt >> 1][(nt & 1) * 4 + j] = sb[j]; }
 #ifndef SV_AT_PROBE_NOPS
-        Ps[o] = (__bf16)s[nt][j]; Ss[o] = (__bf16)dp[nt][j];
+      *reinterpret_cast<bf16x4*>(Ps + qrow * LDP_H + nt * 16 + lg * 4) = pb;     // [query][key] rows: four consecutive keys per lane
+      *reinterpret_cast<bf16x4*>(Ss + qrow * LDP_H + nt * 16 + lg * 4) = sb;
 #endif
-      }
-    __syncthreads();
-    // ---- rows of this wave: keys 16w.. for dV = P^T dO and dK = dS^T (scale Q); queries 16w.. for dQ = scale dS K
-    f32x4 av[2], ak[2], aq[2];
+    }
+    // ---- dQ = scale dS K for this wave's queries, from the registers: lane -> query lr, head channels 8 lg + 4 nt + j
+    f32x4 aq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) { av[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ak[nt] = av[nt]; aq[nt] = av[nt]; }
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const __bf16* src = Ks + (2 * ks * 16 + lg * 4 + (lr >> 2)) * LDQ_H + (lr & 3) * 8 + nt * 4;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src + 16 * LDQ_H));
+        const bf16x8 kT = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        aq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsf[ks], aq[nt], 0, 0, 0);
+      }
+    if (qrow_ok) {
+      AT* dst = p.dqkv + (size_t)tm.row(qrow) * ld + colq + lg * 8;
+      st4f(dst, make_float4(aq[0][0] * p.scale, aq[0][1] * p.scale, aq[0][2] * p.scale, aq[0][3] * p.scale));
+      st4f(dst + 4, make_float4(aq[1][0] * p.scale, aq[1][1] * p.scale, aq[1][2] * p.scale, aq[1][3] * p.scale));
+    }
+    __syncthreads();
+    // ---- this wave's 16 KEYS: dV = P^T dO and dK = dS^T (scale Q), contractions over all 64 queries of the tiles
+    f32x4 av[2], ak[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) { av[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ak[nt] = av[nt]; }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const bf16x8 pT = tr_frag(Ps, LDP_H, ks * 32, wave * 16, lane);        // A[key][q]
       const bf16x8 sT = tr_frag(Ss, LDP_H, ks * 32, wave * 16, lane);        // A[key][q]
-      const bf16x8 sR = *reinterpret_cast<const bf16x8*>(Ss + (wave * 16 + lr) * LDP_H + ks * 32 + lg * 8);   // A[q][key]
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const bf16x8 bd = tr_frag(Ds, LDQ_H, ks * 32, nt * 16, lane);        // dO[q][d]
         const bf16x8 bq = tr_frag(Qs, LDQ_H, ks * 32, nt * 16, lane);        // (scale Q)[q][d]
-        const bf16x8 bk = tr_frag(Ks, LDQ_H, ks * 32, nt * 16, lane);        // K[key][d]
         // operands swapped: the accumulators are the transposed blocks, X[row = lr][d = lg*4 + j] (vector stores below)
         av[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bd, pT, av[nt], 0, 0, 0);
         ak[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, sT, ak[nt], 0, 0, 0);
-        aq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk, sR, aq[nt], 0, 0, 0);
       }
     }
     {
-      const int t = wave * 16 + lr;               // a key row for dV / dK, a query row for dQ
+      const int t = wave * 16 + lr;               // a key row
       if (t < WT) {
         AT* dst = p.dqkv + (size_t)tm.row(t) * ld + colq + lg * 4;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          st4f(dst + nt * 16, make_float4(aq[nt][0] * p.scale, aq[nt][1] * p.scale, aq[nt][2] * p.scale, aq[nt][3] * p.scale));
           st4f(dst + p.C + nt * 16, make_float4(ak[nt][0], ak[nt][1], ak[nt][2], ak[nt][3]));
           st4f(dst + 2 * p.C + nt * 16, make_float4(av[nt][0], av[nt][1], av[nt][2], av[nt][3]));
         }
@@ -1045,20 +1108,18 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
   }
   // ---- relative-position-bias gradient: registers -> LDS (once per workgroup) -> one atomic per table entry
   __syncthreads();
+  if (qrow_ok) {
+    const int qy = qrow / 7, qx = qrow - qy * 7;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int q = wave * 16 + lg * 4 + j;
-    if (q < WT) {
-      const int qy = q / 7, qx = q - qy * 7;
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int key = nt * 16 + lr;
+      for (int j = 0; j < 4; ++j) {
+        const int key = nt * 16 + lg * 4 + j;
         if (key < WT) {
           const int ky = key / 7, kx = key - ky * 7;
           atomicAdd(dbt + (qy - ky + 6) * 13 + (qx - kx + 6), dsum[nt][j]);
         }
       }
-    }
   }
   __syncthreads();
   float* dst = dt_ws ? dt_ws + (size_t)(chunk % ATTN_DT_SLOTS) * 169 * p.heads : p.dtable;
