@@ -470,6 +470,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int row0, 
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// the same fragment with the columns of a 32-wide head tile permuted: MFMA row lr <- column 8 (lr >> 2) + 4 nt + (lr & 3), so that the two
+// 16-column blocks nt = 0, 1 of a transposed accumulator leave the 8 CONSECUTIVE columns 8 lg .. 8 lg + 7 of a row in one lane (16-byte stores)
+__device__ __forceinline__ bf16x8 tr_frag_perm(const __bf16* tile, int ld, int row0, int nt, int lane) {
+  const int lr = lane & 15, lg = lane >> 4;
+  const __bf16* src = tile + (row0 + lg * 8 + (lr >> 2)) * ld + (lr & 3) * 8 + nt * 4;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src + 4 * ld));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // ------------------------------------------------------------------------------------------------
 // cross-view attention core.  qkv: [B*V*P, 3R] channels-last rows (img, pos), R = heads*hd reduced channels;
 // feature of (view, head) = all (pos, c) with c in the head's hd channels -> F = P*hd (288).
@@ -684,6 +694,26 @@ static inline int wg_tasks_per_block(int ntasks, int heads, int blocks_per_cu) {
 }
 static inline unsigned wg_grid(int nchunks, int heads) { return 8u * (unsigned)heads * (unsigned)((nchunks + 7) / 8); }
 
+// A thread's piece of a [64 tokens][32 channels] head tile in the cooperative (256-thread) loads: CV consecutive channels of one token row -
+// 16 bytes of bf16 rows (one pass over the tile), 4 floats of fp32 rows (two passes)
+template <typename AT> struct HeadChunk {
+  static constexpr int CV = sizeof(AT) == 2 ? 8 : 4, TPRW = HD / CV, NIT = 64 * TPRW / 256;
+  typedef typename VecN<AT, CV>::type RV;
+  static __device__ __forceinline__ int row(int tid, int it) { return tid / TPRW + (256 / TPRW) * it; }
+  static __device__ __forceinline__ int ch(int tid) { return (tid % TPRW) * CV; }
+};
+__device__ __forceinline__ void put_chunk(__bf16* dst, const float4& v, float mul) {
+  bf16x4 b;
+  b[0] = (__bf16)(v.x * mul); b[1] = (__bf16)(v.y * mul); b[2] = (__bf16)(v.z * mul); b[3] = (__bf16)(v.w * mul);
+  *reinterpret_cast<bf16x4*>(dst) = b;
+}
+__device__ __forceinline__ void put_chunk(__bf16* dst, const bf16x8& v, float mul) {
+  bf16x8 b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b[j] = (__bf16)((float)v[j] * mul);
+  *reinterpret_cast<bf16x8*>(dst) = b;
+}
+
 template <typename AT>
 __global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<AT> p) {
   // q (scaled) | k | v of the window's head, row-major [token][32 (+8)] bf16.  The products are taken with swapped operands (keys / V^T as
@@ -723,21 +753,18 @@ __global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<
     if (task >= p.ntasks) break;                                         // uniform over the workgroup
     const TokMap tm = task_map(task, nW, nWx, p.H, p.W, p.shift);
     __syncthreads();                                                     // previous window's tiles are consumed
+    typedef HeadChunk<AT> HC;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int r = (tid >> 3) + 32 * it, ch = (tid & 7) * 4;
-      float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;   // rows >= 49: zeros (finite values under zero probabilities)
+    for (int it = 0; it < HC::NIT; ++it) {
+      const int r = HC::row(tid, it), ch = HC::ch(tid);
+      typename HC::RV q4 = VecN<AT, HC::CV>::zero(), k4 = q4, v4 = q4;   // rows >= 49: zeros (finite values under zero probabilities)
       if (r < WT) {
         const AT* src = p.qkv + (size_t)tm.row(r) * ld + colq + ch;
-        q4 = ld4f(src); k4 = ld4f(src + p.C); v4 = ld4f(src + 2 * p.C);
+        q4 = VecN<AT, HC::CV>::load(src); k4 = VecN<AT, HC::CV>::load(src + p.C); v4 = VecN<AT, HC::CV>::load(src + 2 * p.C);
       }
-      bf16x4 qb, kb, vb;
-      qb[0] = (__bf16)(q4.x * qscale); qb[1] = (__bf16)(q4.y * qscale); qb[2] = (__bf16)(q4.z * qscale); qb[3] = (__bf16)(q4.w * qscale);
-      kb[0] = (__bf16)k4.x; kb[1] = (__bf16)k4.y; kb[2] = (__bf16)k4.z; kb[3] = (__bf16)k4.w;
-      vb[0] = (__bf16)v4.x; vb[1] = (__bf16)v4.y; vb[2] = (__bf16)v4.z; vb[3] = (__bf16)v4.w;
-      *reinterpret_cast<bf16x4*>(Qs + r * LDQ_H + ch) = qb;
-      *reinterpret_cast<bf16x4*>(Ks + r * LDQ_H + ch) = kb;
-      *reinterpret_cast<bf16x4*>(Vs + r * LDQ_H + ch) = vb;
+      put_chunk(Qs + r * LDQ_H + ch, q4, qscale);
+      put_chunk(Ks + r * LDQ_H + ch, k4, 1.f);
+      put_chunk(Vs + r * LDQ_H + ch, v4, 1.f);
     }
     __syncthreads();
     f32x4 s[4];
@@ -792,9 +819,8 @@ __global__ __launch_bounds__(256, 4) void win_attn_fwd_wg_kernel(const WinArgsT<
         o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ks], o[nt], 0, 0, 0);
       }
     if (qok) {   // lane: query lr, head channels 8 lg .. 8 lg + 7 (block nt holds 8 lg + 4 nt + j): one 16-byte vector of bf16 rows
-      AT* dst = p.out + (size_t)tm.row(q) * p.C + colq + lg * 8;
-      st4f(dst, make_float4(o[0][0], o[0][1], o[0][2], o[0][3]));
-      st4f(dst + 4, make_float4(o[1][0], o[1][1], o[1][2], o[1][3]));
+      const float ov[8] = {o[0][0], o[0][1], o[0][2], o[0][3], o[1][0], o[1][1], o[1][2], o[1][3]};
+      stnf<8>(p.out + (size_t)tm.row(q) * p.C + colq + lg * 8, ov);
     }
   }
 }
@@ -950,14 +976,15 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
   const long long task0 = (long long)chunk * p.tasks_per_wave;
   // the next window's q / k / v / dO vectors travel in registers while this window is contracted: a window is
   // load -> barrier -> MFMA -> softmax -> barrier -> MFMA -> store, and three workgroups per CU do not hide a global round trip
-  typedef typename V4<AT>::type RV;
-  RV rq[2], rk[2], rv[2], rd[2];
+  typedef HeadChunk<AT> HC;
+  typedef typename HC::RV RV;
+  RV rq[HC::NIT], rk[HC::NIT], rv[HC::NIT], rd[HC::NIT];
   auto fetch = [&](long long task) {
     const TokMap tn = task_map(task, nW, nWx, p.H, p.W, p.shift);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int r = (tid >> 3) + 32 * it, ch = (tid & 7) * 4;
-      rq[it] = V4<AT>::zero(); rk[it] = rq[it]; rv[it] = rq[it]; rd[it] = rq[it];
+    for (int it = 0; it < HC::NIT; ++it) {
+      const int r = HC::row(tid, it), ch = HC::ch(tid);
+      rq[it] = VecN<AT, HC::CV>::zero(); rk[it] = rq[it]; rv[it] = rq[it]; rd[it] = rq[it];
 #ifdef SV_AT_PROBE_NOFETCH
       if (r < 0) {
 #else
@@ -965,18 +992,12 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
 #endif
         const size_t row = tn.row(r);
         const AT* src = p.qkv + row * ld + colq + ch;
-        rq[it] = V4<AT>::load(src); rk[it] = V4<AT>::load(src + p.C); rv[it] = V4<AT>::load(src + 2 * p.C);
-        rd[it] = V4<AT>::load(p.dout + row * p.C + colq + ch);
+        rq[it] = VecN<AT, HC::CV>::load(src); rk[it] = VecN<AT, HC::CV>::load(src + p.C); rv[it] = VecN<AT, HC::CV>::load(src + 2 * p.C);
+        rd[it] = VecN<AT, HC::CV>::load(p.dout + row * p.C + colq + ch);
       }
     }
   };
-  auto put = [&](__bf16* dst, const RV& v, int it, float mul) {
-    const int r = (tid >> 3) + 32 * it, ch = (tid & 7) * 4;
-    const float4 f = to_f4(v);
-    bf16x4 b;
-    b[0] = (__bf16)(f.x * mul); b[1] = (__bf16)(f.y * mul); b[2] = (__bf16)(f.z * mul); b[3] = (__bf16)(f.w * mul);
-    *reinterpret_cast<bf16x4*>(dst + r * LDQ_H + ch) = b;
-  };
+  auto put = [&](__bf16* dst, const RV& v, int it, float mul) { put_chunk(dst + HC::row(tid, it) * LDQ_H + HC::ch(tid), v, mul); };
   if (task0 < p.ntasks) fetch(task0);
   for (int tt = 0; tt < p.tasks_per_wave; ++tt) {
     const long long task = task0 + tt;
@@ -984,7 +1005,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
     const TokMap tm = task_map(task, nW, nWx, p.H, p.W, p.shift);
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 2; ++it) { put(Qs, rq[it], it, p.scale); put(Ks, rk[it], it, 1.f); put(Vs, rv[it], it, 1.f); put(Ds, rd[it], it, 1.f); }
+    for (int it = 0; it < HC::NIT; ++it) { put(Qs, rq[it], it, p.scale); put(Ks, rk[it], it, 1.f); put(Vs, rv[it], it, 1.f); put(Ds, rd[it], it, 1.f); }
     __syncthreads();
     if (tt + 1 < p.tasks_per_wave && task + 1 < p.ntasks) fetch(task + 1);
     // ---- this wave's 16 queries: S^T = K (scale Q)^T, dP^T = V dO^T, P = softmax, dS = P o (dP - rowsum(dP o P))
@@ -1072,9 +1093,9 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
         aq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsf[ks], aq[nt], 0, 0, 0);
       }
     if (qrow_ok) {
-      AT* dst = p.dqkv + (size_t)tm.row(qrow) * ld + colq + lg * 8;
-      st4f(dst, make_float4(aq[0][0] * p.scale, aq[0][1] * p.scale, aq[0][2] * p.scale, aq[0][3] * p.scale));
-      st4f(dst + 4, make_float4(aq[1][0] * p.scale, aq[1][1] * p.scale, aq[1][2] * p.scale, aq[1][3] * p.scale));
+      const float qv[8] = {aq[0][0] * p.scale, aq[0][1] * p.scale, aq[0][2] * p.scale, aq[0][3] * p.scale,
+                           aq[1][0] * p.scale, aq[1][1] * p.scale, aq[1][2] * p.scale, aq[1][3] * p.scale};
+      stnf<8>(p.dqkv + (size_t)tm.row(qrow) * ld + colq + lg * 8, qv);
     }
     __syncthreads();
     // ---- this wave's 16 KEYS: dV = P^T dO and dK = dS^T (scale Q), contractions over all 64 queries of the tiles
@@ -1087,9 +1108,9 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
       const bf16x8 sT = tr_frag(Ss, LDP_H, ks * 32, wave * 16, lane);        // A[key][q]
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const bf16x8 bd = tr_frag(Ds, LDQ_H, ks * 32, nt * 16, lane);        // dO[q][d]
-        const bf16x8 bq = tr_frag(Qs, LDQ_H, ks * 32, nt * 16, lane);        // (scale Q)[q][d]
-        // operands swapped: the accumulators are the transposed blocks, X[row = lr][d = lg*4 + j] (vector stores below)
+        const bf16x8 bd = tr_frag_perm(Ds, LDQ_H, ks * 32, nt, lane);        // dO[q][d]
+        const bf16x8 bq = tr_frag_perm(Qs, LDQ_H, ks * 32, nt, lane);        // (scale Q)[q][d]
+        // operands swapped: the accumulators are the transposed blocks, X[row = lr][d = 8 lg + 4 nt + j] (16-byte stores below)
         av[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bd, pT, av[nt], 0, 0, 0);
         ak[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, sT, ak[nt], 0, 0, 0);
       }
@@ -1097,12 +1118,11 @@ __global__ __launch_bounds__(256, 3) void win_attn_bwd_wg_kernel(const WinArgsT<
     {
       const int t = wave * 16 + lr;               // a key row
       if (t < WT) {
-        AT* dst = p.dqkv + (size_t)tm.row(t) * ld + colq + lg * 4;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          st4f(dst + p.C + nt * 16, make_float4(ak[nt][0], ak[nt][1], ak[nt][2], ak[nt][3]));
-          st4f(dst + 2 * p.C + nt * 16, make_float4(av[nt][0], av[nt][1], av[nt][2], av[nt][3]));
-        }
+        AT* dst = p.dqkv + (size_t)tm.row(t) * ld + colq + lg * 8;
+        const float kv[8] = {ak[0][0], ak[0][1], ak[0][2], ak[0][3], ak[1][0], ak[1][1], ak[1][2], ak[1][3]};
+        const float vv[8] = {av[0][0], av[0][1], av[0][2], av[0][3], av[1][0], av[1][1], av[1][2], av[1][3]};
+        stnf<8>(dst + p.C, kv);
+        stnf<8>(dst + 2 * p.C, vv);
       }
     }
   }
