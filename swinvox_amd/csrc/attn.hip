@@ -58,17 +58,13 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
-// all-reduce over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48) on the VALU: v_permlane16_swap exchanges the odd rows of one
-// operand with the even rows of the other, v_permlane32_swap the upper half with the lower half - with both operands the same register the
-// two results are "mine" and "the partner's" (no LDS crossbar round trip as ds_bpermute / __shfl_xor would take)
-// (inline asm: through __builtin_amdgcn_permlane16_swap hipcc 7.2 propagates the copy it made for the second operand across the
-// instruction - which rewrites BOTH registers - and adds the first result to itself; s_nop 1 covers the VALU-write -> permlane-read hazard
-// the compiler would have covered)
+// all-reduce over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48) on the VALU: the v_permlane16_swap / v_permlane32_swap
+// exchanges of common.h (no LDS crossbar round trip as ds_bpermute / __shfl_xor would take)
 template <typename OP> __device__ __forceinline__ float lanegroup_allreduce(float v, OP op) {
   float w = v;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+  permlane16_pair(v, w);
   v = op(v, w); w = v;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+  permlane32_pair(v, w);
   return op(v, w);
 }
 

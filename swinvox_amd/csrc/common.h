@@ -101,18 +101,35 @@ int check_launch(const char* what);
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // all-reduce over the 16 lanes of a DPP row with VALU moves (quad_perm xor 1, xor 2, row_half_mirror, row_mirror); the two steps across rows
-// go through __shfl_xor (LDS crossbar).  Every lane gets the result.
+// are v_permlane16_swap / v_permlane32_swap exchanges (VALU too: no LDS crossbar round trip as __shfl_xor = ds_bpermute takes).  Every lane
+// gets the result.
 template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
+// v_permlane16_swap exchanges the odd 16-lane rows of its first register with the even rows of the second, v_permlane32_swap the upper
+// half of the first with the lower half of the second: with the same value in both, the registers afterwards hold "mine" and "the
+// partner's" (lane ^ 16 / lane ^ 32) in some order - enough for a commutative reduction (scripts/probes/permlane_swap_probe.hip prints the
+// mapping).  Inline asm: through __builtin_amdgcn_permlane16_swap hipcc 7.2 propagates the copy it makes for the second operand across the
+// instruction - which rewrites BOTH registers - and combines the first result with itself; s_nop 1 covers the VALU-write -> permlane-read
+// hazard the compiler would have covered.
+__device__ __forceinline__ void permlane16_pair(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void permlane32_pair(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+// one step of an all-reduce (sum) over the lanes that share lane % CW: v + the value of a lane O away.  O = 16 / 32: the exchanges above;
+// O < 16: a DPP rotation of the 16-lane row (rotations by CW, 2 CW, ... 8 visit the whole coset, as the xor steps would)
+template <int O> __device__ __forceinline__ float lane_step_add(float v) {
+  if constexpr (O == 32) { float w = v; permlane32_pair(v, w); return v + w; }
+  else if constexpr (O == 16) { float w = v; permlane16_pair(v, w); return v + w; }
+  else return v + dpp_move<0x120 + O>(v);   // row_ror:O
+}
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_move<0xB1>(v); v += dpp_move<0x4E>(v); v += dpp_move<0x141>(v); v += dpp_move<0x140>(v);
-  v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+  v = lane_step_add<16>(v); v = lane_step_add<32>(v);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_move<0xB1>(v)); v = fmaxf(v, dpp_move<0x4E>(v)); v = fmaxf(v, dpp_move<0x141>(v)); v = fmaxf(v, dpp_move<0x140>(v));
-  v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
+  { float w = v; permlane16_pair(v, w); v = fmaxf(v, w); }
+  { float w = v; permlane32_pair(v, w); v = fmaxf(v, w); }
   return v;
 }
 

@@ -278,10 +278,16 @@ __device__ __forceinline__ void epilogue_rows(const IGemmArgs& p, const ClassInf
   }
   if (e.stats) {  // per-channel sum / sumsq of what was stored: lanes sharing a column group, then the waves, then ONE
                   // double atomic per column per workgroup into one of SV_BN_SLOTS accumulator slots (spreads contention)
+    // lanes that share a column group (lane % CW): DPP row rotations and v_permlane swaps (common.h) - the 2 x CV x log2(64 / CW)
+    // __shfl_xor round trips through the LDS crossbar this used to be cost the BatchNorm producers up to 20 % of their time
 #pragma unroll
     for (int j = 0; j < CV; ++j) {
-#pragma unroll
-      for (int o = CW; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+      if constexpr (CW <= 1) { s1[j] = lane_step_add<1>(s1[j]); s2[j] = lane_step_add<1>(s2[j]); }
+      if constexpr (CW <= 2) { s1[j] = lane_step_add<2>(s1[j]); s2[j] = lane_step_add<2>(s2[j]); }
+      if constexpr (CW <= 4) { s1[j] = lane_step_add<4>(s1[j]); s2[j] = lane_step_add<4>(s2[j]); }
+      if constexpr (CW <= 8) { s1[j] = lane_step_add<8>(s1[j]); s2[j] = lane_step_add<8>(s2[j]); }
+      if constexpr (CW <= 16) { s1[j] = lane_step_add<16>(s1[j]); s2[j] = lane_step_add<16>(s2[j]); }
+      if constexpr (CW <= 32) { s1[j] = lane_step_add<32>(s1[j]); s2[j] = lane_step_add<32>(s2[j]); }
     }
     if ((lane / CW) == 0 || CW >= 64) {
 #pragma unroll
