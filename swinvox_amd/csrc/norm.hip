@@ -58,8 +58,8 @@ template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {   // sum over the LPR (16 / 32 / 64) lanes that share a row, every lane gets it
   // inside a 16-lane DPP row: quad_perm xor 1, xor 2, row_half_mirror, row_mirror (VALU moves, no LDS crossbar round trips)
   v += ln_dpp_mov<0xB1>(v); v += ln_dpp_mov<0x4E>(v); v += ln_dpp_mov<0x141>(v); v += ln_dpp_mov<0x140>(v);
-#pragma unroll
-  for (int o = 16; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
+  if constexpr (LPR > 16) v = lane_step_add<16>(v);     // across rows: v_permlane16 / 32 swaps (common.h), VALU as well
+  if constexpr (LPR > 32) v = lane_step_add<32>(v);
   return v;
 }
 

@@ -171,14 +171,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void swin_mlp_fwd_kernel(const MlpArg
 #pragma unroll
       for (int j = 0; j < 8; ++j) { xv[f][j] = (float)raw[j]; s += xv[f][j]; }
     }
-    s += __shfl_xor(s, 32, 64);
+    s = lane_step_add<32>(s);
     const float mean = s * (1.f / C);
     float q = 0.f;
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const float d = xv[f][j] - mean; q += d * d; }
-    q += __shfl_xor(q, 32, 64);
+    q = lane_step_add<32>(q);
     const float rstd = rsqrtf(q * (1.f / C) + p.eps);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -325,14 +325,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void swin_mlp_bwd_kernel(const MlpArg
 #pragma unroll
         for (int j = 0; j < 8; ++j) { xv[f][j] = (float)raw[j]; s += xv[f][j]; dyb[f][j] = (__bf16)(sc * (float)dr[j]); }
       }
-      s += __shfl_xor(s, 32, 64);
+      s = lane_step_add<32>(s);
       mean = s * (1.f / C);
       float q = 0.f;
 #pragma unroll
       for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float d = xv[f][j] - mean; q += d * d; }
-      q += __shfl_xor(q, 32, 64);
+      q = lane_step_add<32>(q);
       rstd = rsqrtf(q * (1.f / C) + p.eps);
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
@@ -433,8 +433,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void swin_mlp_bwd_kernel(const MlpArg
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the 8 reduction chains of one channel group together (interleaving all 96 spills)
       }
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
+    s1 = lane_step_add<32>(s1);
+    s2 = lane_step_add<32>(s2);
     s1 *= (1.f / C); s2 *= (1.f / C);
     if (valid) {
 #pragma unroll
@@ -565,14 +565,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void swin_mlp_wgrad_kernel(c
 #pragma unroll
         for (int j = 0; j < 8; ++j) s1 += (float)v[u][j];
       }
-      s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+      s1 += dpp_move<0xB1>(s1); s1 += dpp_move<0x4E>(s1);
       const float mean = s1 * (1.f / C);
       float s2 = 0.f;
 #pragma unroll
       for (int u = 0; u < C / 32; ++u)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float d = (float)v[u][j] - mean; s2 += d * d; }
-      s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+      s2 += dpp_move<0xB1>(s2); s2 += dpp_move<0x4E>(s2);
       const float rstd = rsqrtf(s2 * (1.f / C) + p.eps);
       const float sc = t0 + row < t_img ? sc_lo : sc_hi;
 #pragma unroll
@@ -676,8 +676,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void swin_mlp_wgrad_kernel(c
 #pragma unroll
   for (int hb = 0; hb < NHB; ++hb) {
     float v = db1acc[hb];
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    v = lane_step_add<16>(v);
+    v = lane_step_add<32>(v);
     if (lg == 0) atomicAdd(p.db1 + h0 + 16 * hb + lr, v);
   }
   if (hg == 0 && tid < C) atomicAdd(p.db2 + tid, db2acc);
