@@ -28,4 +28,4 @@ for H, heads in ((56, 3), (28, 6), (14, 12), (7, 24)):
         tb = timeit(lambda: call("sv_window_attention_bwd", ptr(qkv), ptr(table), ptr(dout), ptr(dqkv), ptr(dt), ptr(ws), I, H, H, C, heads, shift, hip.MATH_BF16))
         mb = rows * C * 2 / 1e6
         fl = 4.0 * rows * 49 * C   # QK^T + AV, 49-token algorithmic count
-        print(f"H={H:3d} heads={heads:2d} shift={shift}  fwd {tf:7.1f} us ({4*mb/tf*1e3:6.0f} GB/s, {fl/tf/1e6:6.1f} TF/s)   bwd {tb:7.1f} us ({8*mb/tb*1e3:6.0f} GB/s, {2.5*fl/tb/1e6:6.1f} TF/s)")
+        print(f"H={H:3d} heads={heads:2d} shift={shift}  fwd {tf:7.1f} us ({4*mb/tf*1e3:6.0f} GB/s, {fl/tf/1e6:6.1f} TF/s)   bwd {tb:7.1f} us ({7*mb/tb*1e3:6.0f} GB/s, {2.5*fl/tb/1e6:6.1f} TF/s)")
