@@ -163,11 +163,22 @@ def main():
     torch.manual_seed(4321 + rank)       # per-rank stream for dropout / drop-path seeds
     order = [nets[3], nets[2], nets[1], nets[0]]      # the order the modules' gradients complete in
     # eager: buckets launched from hooks inside the backward; graph replay: reduce_all() after the replay
-    # encoder parameter groups start their all-reduce inside the encoder backward (RCCL: stream-ordered, never blocks the host).  The gloo
-    # rehearsal backend stages CUDA tensors through the host and blocks inside the backward (measured 2 ranks on one card, B = 4: 6.3 s per
-    # step with early groups, 0.79 s with per-module hooks only, 0.18 s with reduce-after-replay), so it gets the per-module hooks only
-    early = os.environ.get("SV_DP_EARLY", "1" if backend == "nccl" else "0") != "0"
+    # Default = the plain schedule (a bucket starts from the post-accumulate hook of its last gradient): the one that has run on a GPU.
+    # SV_DP_EARLY=1 opts in to the encoder's early parameter groups (their all-reduce starts inside the encoder backward on a staging
+    # stream; <= 4 ms of a 113 ms step at stake) - kept off until a hardware RCCL run of the plain schedule exists.
+    early = os.environ.get("SV_DP_EARLY", "0") != "0"
     reducer = GradAllReducer(order, hooks=not use_graph, early_groups=early) if world > 1 else None
+    param_checksum_spread = 0.0
+    if world > 1:
+        # after construction (rank 0's parameters broadcast) every rank must hold the same model: all-reduce a checksum, max - min = 0.
+        # On a mismatch the process exits non-zero; nothing is retried in a process that has touched the GPU.
+        cs = torch.stack([p.detach().double().sum() for n in nets for p in n.parameters()]).sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        param_checksum_spread = float(hi - lo)
+        if param_checksum_spread != 0.0:
+            raise SystemExit(f"bench.py: ranks hold different parameters after the broadcast (checksum spread {param_checksum_spread})")
 
     B, V = args.batch, args.views
     g = torch.Generator().manual_seed(rank)
@@ -293,9 +304,13 @@ def main():
         try:
             import glob
             summ_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
-            pm = json.load(open(summ_files[-1])).get("pmc_traffic", {})
-            traffic = [v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if k.startswith("contraction engine")][0]
+            prof = json.load(open(summ_files[-1]))
             traffic_src = os.path.basename(summ_files[-1])
+            if prof.get("kernel_source_hash") == hip.kernel_source_hash():
+                pm = prof.get("pmc_traffic", {})
+                traffic = [v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if k.startswith("contraction engine")][0]
+            else:   # the committed counters describe another build of the kernels: do not quote them for this one
+                traffic_src += f" (kernel sources changed since: profile {prof.get('kernel_source_hash')}, tree {hip.kernel_source_hash()})"
         except Exception:
             traffic = None
         out = {
@@ -342,6 +357,7 @@ def main():
             "model_flops_tflops_per_gpu": (3 * FWD_GFLOP_PER_VIEW.get(V, 19.4) * 1e9 * value / world / 1e12) if args.variant == "tiny" else None,
             "data_parallel": {"world_size": (dist.get_world_size() if world > 1 else 1), "backend": (backend if world > 1 else None),
                               "payload_bytes": dp_stats["payload_bytes"] if dp_stats else 0, "buckets": dp_stats["buckets"] if dp_stats else 0,
+                              "bucket_bytes": dp_stats["bucket_bytes"] if dp_stats else [], "param_checksum_spread": param_checksum_spread,
                               "allreduce_exposed_ms_per_step": (dp_stats["exposed_ms_per_step"] or 0.0) if dp_stats else 0.0,
                               "allreduce_isolated_ms": ar_iso_ms or 0.0,
                               "overlap": None if world == 1 else ("none: all buckets are reduced after the graph replay" if use_graph else

@@ -50,7 +50,10 @@ def main():
     ap.add_argument("--steps-in-trace", type=int, default=4)
     ap.add_argument("--steps-in-pmc", type=int, default=2)
     a = ap.parse_args()
-    out = {"tag": a.tag}
+    import sys
+    sys.path.insert(0, ROOT)
+    from swinvox_amd.hip import kernel_source_hash
+    out = {"tag": a.tag, "kernel_source_hash": kernel_source_hash()}    # the build the counters describe (bench.py checks it)
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     if a.stats:
         f = glob.glob(os.path.join(a.stats, "*", "*_kernel_stats.csv"))[0]

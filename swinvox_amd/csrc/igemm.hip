@@ -18,6 +18,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <atomic>
+#include <mutex>
 
 namespace sv {
 
@@ -1267,17 +1268,32 @@ static int check_common(const sv_geom* g, const sv_epilogue* e, const void* in, 
 // scheduler counters of the wide kernel: 16 ints per launch slot, zero on entry, zeroed again by the launch's last workgroup.  A slot is
 // reused after GW_SLOTS launches of this process - far more than a device queue holds in flight.
 constexpr int GW_SLOTS = 4096;
-static int* gemm_wide_counters();
-static bool gemm_wide_counters_ready() { static const bool ok = gemm_wide_counters() != nullptr; return ok; }
-static int* gemm_wide_counters() {
-  static int* buf = [] {
-    int* b = nullptr;
-    if (hipMalloc(&b, sizeof(int) * 16 * GW_SLOTS) != hipSuccess || hipMemset(b, 0, sizeof(int) * 16 * GW_SLOTS) != hipSuccess) return (int*)nullptr;
-    hipDeviceSynchronize();
-    return b;
-  }();
-  static std::atomic<unsigned> next{0};
-  return buf ? buf + 16 * (next.fetch_add(1) % GW_SLOTS) : nullptr;
+// One buffer PER DEVICE (ops._CallContext allows one thread per device in a process): a launch on device 1 must not hand the scheduler a
+// pointer into device 0's memory.  The table is filled lazily under a mutex; the slot cursor is per device too.
+struct GwCounters { int* buf = nullptr; bool tried = false; std::atomic<unsigned> next{0}; };
+static GwCounters* gemm_wide_counter_table() {
+  static GwCounters tab[16];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  GwCounters& c = tab[dev];
+  if (!c.tried) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!c.tried) {
+      int* b = nullptr;
+      if (hipMalloc(&b, sizeof(int) * 16 * GW_SLOTS) == hipSuccess && hipMemset(b, 0, sizeof(int) * 16 * GW_SLOTS) == hipSuccess) {
+        hipDeviceSynchronize();
+        c.buf = b;
+      }
+      c.tried = true;
+    }
+  }
+  return c.buf ? &c : nullptr;
+}
+static bool gemm_wide_counters_ready() { return gemm_wide_counter_table() != nullptr; }
+static int* gemm_wide_counters() {     // next launch slot of the current device
+  GwCounters* c = gemm_wide_counter_table();
+  return c ? c->buf + 16 * (c->next.fetch_add(1) % GW_SLOTS) : nullptr;
 }
 
 // the wide kernel takes the dense layers whose K loop is worth a DMA ring and whose tile count fills the chip;

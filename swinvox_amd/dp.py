@@ -43,7 +43,10 @@ def sync_module_states(modules: Sequence[torch.nn.Module], group=None, src: int 
 
 class GradAllReducer:
     def __init__(self, modules: Sequence[torch.nn.Module], bucket_bytes: int = 64 << 20, group=None, sync_states: bool = True,
-                 hooks: bool = True, early_groups: bool = True):
+                 hooks: bool = True, early_groups: bool = False):
+        """early_groups (opt-in): buckets of a module that announces parameter groups from inside its backward start there.  The
+        default is the plain schedule - one post-accumulate hook per parameter, a bucket starts when its last gradient has been
+        accumulated - which is the one that has run on a GPU (under gloo) and in the CPU tests."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.modules = list(modules)
@@ -93,6 +96,28 @@ class GradAllReducer:
         self._countdown = {bi: len(b) for bi, b in enumerate(self.buckets)}
         self._launched = set()
         self._pending = []
+        self._early_range = {}        # bucket index -> (first byte, end byte) of the buffer slice an early hook reduced
+
+    def _covered(self, bi: int) -> bool:
+        """True when every p.grad of bucket `bi` lies inside the slice its early hook reduced (autograd stole the GradStore view)."""
+        rng = self._early_range.get(bi)
+        if rng is None:
+            return True
+        for p in self.buckets[bi]:
+            g = p.grad
+            if g is None or not (rng[0] <= g.data_ptr() and g.data_ptr() + g.numel() * g.element_size() <= rng[1]):
+                return False
+        return True
+
+    def _check_early(self, bi: int):
+        """An early hook reduced the backward's gradient buffer.  That IS p.grad only when AccumulateGrad takes the returned view
+        as the gradient (p.grad was None).  With a gradient already in place (accumulation over several backward passes,
+        zero_grad(set_to_none=False)) autograd ADDS the reduced view into a different buffer: the sum of a local gradient and a
+        world-summed one, which no later collective can repair - refuse instead of training on it."""
+        if not self._covered(bi):
+            raise RuntimeError(
+                "swinvox_amd.dp: early gradient groups need p.grad to be None before backward() (zero_grad(set_to_none=True), one "
+                "backward per step); construct GradAllReducer(early_groups=False) for gradient accumulation")
 
     def _all_reduce(self, flat, grads):
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -114,6 +139,8 @@ class GradAllReducer:
         bi = self._bucket_of[p]
         self._countdown[bi] -= 1
         if self._countdown[bi] == 0:
+            if bi in self._early_range:
+                self._check_early(bi)
             self._launch(bi)
 
     def _make_early_hook(self, module):
@@ -129,6 +156,7 @@ class GradAllReducer:
                 if flat is None:         # not views of one buffer: leave the bucket to the post-accumulate hooks
                     continue
                 self._launched.add(bi)
+                self._early_range[bi] = (flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size())
                 self._all_reduce(flat, None)
         return hook
 
@@ -145,6 +173,8 @@ class GradAllReducer:
         """Wait for the in-flight buckets, write the averaged gradients back.  Call once after backward()."""
         if self.world == 1:
             return
+        for bi in self._early_range:               # buckets whose post-accumulate hooks did not all fire are checked here
+            self._check_early(bi)
         for bi, left in self._countdown.items():   # parameters that received no gradient this step
             if left > 0 and bi not in self._launched and all(p.grad is not None for p in self.buckets[bi]):
                 self._launch(bi)
@@ -176,6 +206,7 @@ class GradAllReducer:
             if reset:
                 self._exposed = []
         return {"world_size": self.world, "payload_bytes": self.payload_bytes, "buckets": len(self.buckets),
+                "bucket_bytes": [sum(p.numel() * p.element_size() for p in b) for b in self.buckets],
                 "early_groups": sum(len(v) for v in self._early_groups.values()), "exposed_ms_per_step": ms}
 
     def isolated_allreduce_ms(self, repeats: int = 3) -> Optional[float]:

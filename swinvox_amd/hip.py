@@ -141,6 +141,21 @@ def _argtypes(name):
     return list(spec[1]) + ([_I] if name in _ACT_TYPED else []) + [_P]
 
 
+def kernel_source_hash() -> str:
+    """sha256 (16 hex digits) over the kernel sources + the C header: names the build a profile was taken on (bench.py only quotes PMC
+    traffic from a committed profile whose hash equals the current tree's)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "swinvox_hip.h"))
+    for f in files:
+        if os.path.exists(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 EXPORTED_SYMBOLS = sorted(list(_PROTOS.keys()) + ["sv_last_error"])
 
 _lib = None

@@ -102,7 +102,7 @@ class HipModule(nn.Module):
         hook = self.grad_ready_hook
         if hook is None:
             return
-        views = [grads[p] for p in self.grad_groups()[group_index] if p.requires_grad]
+        views = [grads[p] for p in self._grad_groups_cached()[group_index] if p.requires_grad]
         if not views:
             return
         if not views[0].is_cuda:
@@ -118,6 +118,15 @@ class HipModule(nn.Module):
             cs.wait_stream(aw.stream)
         with torch.cuda.stream(cs):
             hook(group_index, views)
+
+    def _grad_groups_cached(self):
+        """grad_groups() walks the parameter tree (~1 ms on the encoder, on the thread that enqueues the backward): cached next to
+        the parameter list and dropped with it when the parameter count changes."""
+        pl = self._param_list()
+        gg = self.__dict__.get("_ggroups")
+        if gg is None or gg[0] != len(pl):
+            gg = self.__dict__["_ggroups"] = (len(pl), self.grad_groups())
+        return gg[1]
 
     def _param_list(self) -> List[torch.Tensor]:
         """Parameters in registration order (cached: walking the module tree costs ~1 ms per call on the encoder).  The

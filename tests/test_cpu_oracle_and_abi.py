@@ -170,6 +170,24 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert exported == declared
 
 
+def test_tile_draw_register_is_untouched_by_the_compiler():
+    """gemm_wide_kernel parks the return of its tile-draw atomic in v167 across inline-asm statements (csrc/igemm.hip); nothing but this
+    check keeps the register allocator out of it.  Disassembles the SHIPPED library: every use of v167 inside every gemm_wide_kernel must
+    be one of the three hand-written instructions, and the checker itself must flag a compiler-style use."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_tile_draw_register", os.path.join(ROOT, "scripts", "check_tile_draw_register.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    if not os.path.exists(chk.OBJDUMP):
+        pytest.skip("llvm-objdump of the ROCm toolchain is not installed here")
+    assert chk.check(hip.LIB_PATH) == []
+    # the checker's own teeth: ranges and plain uses are seen, the three hand-written forms pass
+    assert chk.names_reg("v_pk_mul_f32 v[166:167], v[2:3], v[4:5]") and chk.names_reg("v_add_f32 v1, v167, v2")
+    assert not chk.names_reg("v_mov_b32 v16, v1670") and not chk.names_reg("ds_read_b128 v[160:163], v5")
+    assert chk.allowed("v_mov_b32_e32 v167, -1") == "sentinel" and chk.allowed("v_mov_b32_e32 v32, v167") == "read"
+    assert chk.allowed("global_atomic_add v167, v[8:9], v87, off sc0") == "draw" and chk.allowed("v_add_u32 v167, v1, v2") == ""
+
+
 def test_ctypes_prototypes_match_the_header():
     """Every prototype of include/swinvox_hip.h against the ctypes argument list the host side binds (count and class of
     every argument: pointer / int / long long / float / uint32), and the workspace-size helpers against the host constants

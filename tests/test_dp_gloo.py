@@ -137,7 +137,10 @@ def _early_group_check(rank, world):
     from swinvox_amd.dp import GradAllReducer
     torch.manual_seed(7)
     toy, tail = _Toy(), torch.nn.Linear(3, 2)
-    red = GradAllReducer([tail, toy])
+    plain = GradAllReducer([tail, toy])              # default: per-parameter hooks only, nobody listens to the announcements
+    assert plain.stats()["early_groups"] == 0 and toy.grad_ready_hook is None and len(plain.buckets) == 2
+    plain.remove()
+    red = GradAllReducer([tail, toy], early_groups=True)
     assert len(red.buckets) == 3 and red.stats()["early_groups"] == 2 and toy.grad_ready_hook is not None
     g = torch.Generator().manual_seed(11)
     xs = torch.randn(4, 6, generator=g)
@@ -155,6 +158,18 @@ def _early_group_check(rank, world):
     ref_tail(ref_toy(xs)).square().mean().backward()          # single process, whole batch = mean of the two shards' gradients
     for (k, p), q in zip(list(toy.named_parameters()) + list(tail.named_parameters()), list(ref_toy.parameters()) + list(ref_tail.parameters())):
         assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), (rank, k)
+    # a gradient that is already in place (accumulation, zero_grad(set_to_none=False)): autograd ADDS the reduced view into another
+    # buffer, so the early reduction did not reduce p.grad - the reducer must refuse instead of leaving local + world-summed sums behind
+    try:
+        tail(toy(xs[rank * 2:(rank + 1) * 2])).square().mean().backward()     # second backward, p.grad exists
+        red.finish()
+        raised = False
+    except RuntimeError as e:
+        raised = "early gradient groups" in str(e)
+    assert raised
+    for work, _, _ in red._pending:          # both ranks launched the same collectives before the refusal: let them complete
+        work.wait()
+    red._reset()
     red.remove()
     assert toy.grad_ready_hook is None
 
