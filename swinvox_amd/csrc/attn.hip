@@ -483,7 +483,7 @@ __device__ __forceinline__ bf16x8 tr_frag_perm(const __bf16* tile, int ld, int r
 constexpr int CVA_MAXV = 32, CVA_MAXF = 288;
 
 template <typename AT>
-struct CvaArgsT { const AT* qkv; AT* out; const AT* dout; AT* dqkv; int B, V, P, R, heads, hd; float scale; };
+struct CvaArgsT { const AT* qkv; AT* out; const AT* dout; AT* dqkv; int B, V, P, R, heads, hd, fc; float scale; };
 
 template <typename AT>
 __device__ __forceinline__ size_t cva_off(const CvaArgsT<AT>& p, int b, int v, int f, int head, int which, int ld) {
@@ -491,40 +491,60 @@ __device__ __forceinline__ size_t cva_off(const CvaArgsT<AT>& p, int b, int v, i
   return ((size_t)(b * p.V + v) * p.P + pos) * ld + which * p.R + head * p.hd + c;
 }
 
+// Features are walked in chunks of FC = p.fc <= CVA_MAXF per view (whole positions; one chunk for the 3 x 3 grid of the default
+// ATT_SPATIAL_DOWNSAMPLE_RATIO = 2, six for the 7 x 7 grid of ratio 1): the V x V scores accumulate over the chunks, the second sweep
+// re-loads only when there was more than one chunk.
 template <typename AT>
 __global__ __launch_bounds__(256) void cva_attn_fwd_kernel(const CvaArgsT<AT> p) {
   __shared__ float q[CVA_MAXV * CVA_MAXF], k[CVA_MAXV * CVA_MAXF], v[CVA_MAXV * CVA_MAXF];
   __shared__ float a[CVA_MAXV * CVA_MAXV];
   const int b = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
-  const int F = p.P * p.hd, V = p.V;
-  for (int i = threadIdx.x; i < V * F; i += 256) {
-    const int vi = i / F, f = i - vi * F;
-    q[i] = ldf(p.qkv + cva_off(p, b, vi, f, head, 0, 3 * p.R));
-    k[i] = ldf(p.qkv + cva_off(p, b, vi, f, head, 1, 3 * p.R));
-    v[i] = ldf(p.qkv + cva_off(p, b, vi, f, head, 2, 3 * p.R));
-  }
-  __syncthreads();
-  for (int ij = threadIdx.x; ij < V * V; ij += 256) {
-    const int i = ij / V, j = ij - i * V;
-    float s = 0.f;
-    for (int f = 0; f < F; ++f) s += q[i * F + f] * k[j * F + f];
-    a[ij] = s * p.scale;
+  const int F = p.P * p.hd, V = p.V, FC = p.fc;
+  const bool single = F <= FC;
+  for (int ij = threadIdx.x; ij < V * V; ij += 256) a[ij] = 0.f;
+  for (int f0 = 0; f0 < F; f0 += FC) {
+    const int fc = min(FC, F - f0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < V * fc; i += 256) {
+      const int vi = i / fc, f = i - vi * fc;
+      q[i] = ldf(p.qkv + cva_off(p, b, vi, f0 + f, head, 0, 3 * p.R));
+      k[i] = ldf(p.qkv + cva_off(p, b, vi, f0 + f, head, 1, 3 * p.R));
+      if (single) v[i] = ldf(p.qkv + cva_off(p, b, vi, f0 + f, head, 2, 3 * p.R));
+    }
+    __syncthreads();
+    for (int ij = threadIdx.x; ij < V * V; ij += 256) {
+      const int i = ij / V, j = ij - i * V;
+      float s = 0.f;
+      for (int f = 0; f < fc; ++f) s += q[i * fc + f] * k[j * fc + f];
+      a[ij] += s;
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < V; i += 256) {
     float mx = -3.0e38f;
-    for (int j = 0; j < V; ++j) mx = fmaxf(mx, a[i * V + j]);
+    for (int j = 0; j < V; ++j) { a[i * V + j] *= p.scale; mx = fmaxf(mx, a[i * V + j]); }
     float sum = 0.f;
     for (int j = 0; j < V; ++j) { const float e = expf(a[i * V + j] - mx); a[i * V + j] = e; sum += e; }
     const float inv = 1.f / sum;
     for (int j = 0; j < V; ++j) a[i * V + j] *= inv;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < V * F; i += 256) {
-    const int vi = i / F, f = i - vi * F;
-    float o = 0.f;
-    for (int j = 0; j < V; ++j) o += a[vi * V + j] * v[j * F + f];
-    stf(p.out + cva_off(p, b, vi, f, head, 0, p.R), o);
+  for (int f0 = 0; f0 < F; f0 += FC) {
+    const int fc = min(FC, F - f0);
+    if (!single) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < V * fc; i += 256) {
+        const int vi = i / fc, f = i - vi * fc;
+        v[i] = ldf(p.qkv + cva_off(p, b, vi, f0 + f, head, 2, 3 * p.R));
+      }
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < V * fc; i += 256) {
+      const int vi = i / fc, f = i - vi * fc;
+      float o = 0.f;
+      for (int j = 0; j < V; ++j) o += a[vi * V + j] * v[j * fc + f];
+      stf(p.out + cva_off(p, b, vi, f0 + f, head, 0, p.R), o);
+    }
   }
 }
 
@@ -533,25 +553,31 @@ __global__ __launch_bounds__(256) void cva_attn_bwd_kernel(const CvaArgsT<AT> p)
   __shared__ float q[CVA_MAXV * CVA_MAXF], k[CVA_MAXV * CVA_MAXF], v[CVA_MAXV * CVA_MAXF], d[CVA_MAXV * CVA_MAXF];
   __shared__ float a[CVA_MAXV * CVA_MAXV], ds[CVA_MAXV * CVA_MAXV];
   const int b = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
-  const int F = p.P * p.hd, V = p.V;
-  for (int i = threadIdx.x; i < V * F; i += 256) {
-    const int vi = i / F, f = i - vi * F;
-    q[i] = ldf(p.qkv + cva_off(p, b, vi, f, head, 0, 3 * p.R));
-    k[i] = ldf(p.qkv + cva_off(p, b, vi, f, head, 1, 3 * p.R));
-    v[i] = ldf(p.qkv + cva_off(p, b, vi, f, head, 2, 3 * p.R));
-    d[i] = ldf(p.dout + cva_off(p, b, vi, f, head, 0, p.R));
-  }
-  __syncthreads();
-  for (int ij = threadIdx.x; ij < V * V; ij += 256) {
-    const int i = ij / V, j = ij - i * V;
-    float s = 0.f, da = 0.f;
-    for (int f = 0; f < F; ++f) { s += q[i * F + f] * k[j * F + f]; da += d[i * F + f] * v[j * F + f]; }
-    a[ij] = s * p.scale; ds[ij] = da;
+  const int F = p.P * p.hd, V = p.V, FC = p.fc;
+  const bool single = F <= FC;
+  for (int ij = threadIdx.x; ij < V * V; ij += 256) { a[ij] = 0.f; ds[ij] = 0.f; }
+  for (int f0 = 0; f0 < F; f0 += FC) {
+    const int fc = min(FC, F - f0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < V * fc; i += 256) {
+      const int vi = i / fc, f = i - vi * fc;
+      q[i] = ldf(p.qkv + cva_off(p, b, vi, f0 + f, head, 0, 3 * p.R));
+      k[i] = ldf(p.qkv + cva_off(p, b, vi, f0 + f, head, 1, 3 * p.R));
+      v[i] = ldf(p.qkv + cva_off(p, b, vi, f0 + f, head, 2, 3 * p.R));
+      d[i] = ldf(p.dout + cva_off(p, b, vi, f0 + f, head, 0, p.R));
+    }
+    __syncthreads();
+    for (int ij = threadIdx.x; ij < V * V; ij += 256) {
+      const int i = ij / V, j = ij - i * V;
+      float s = 0.f, da = 0.f;
+      for (int f = 0; f < fc; ++f) { s += q[i * fc + f] * k[j * fc + f]; da += d[i * fc + f] * v[j * fc + f]; }
+      a[ij] += s; ds[ij] += da;
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < V; i += 256) {
     float mx = -3.0e38f;
-    for (int j = 0; j < V; ++j) mx = fmaxf(mx, a[i * V + j]);
+    for (int j = 0; j < V; ++j) { a[i * V + j] *= p.scale; mx = fmaxf(mx, a[i * V + j]); }
     float sum = 0.f;
     for (int j = 0; j < V; ++j) { const float e = expf(a[i * V + j] - mx); a[i * V + j] = e; sum += e; }
     const float inv = 1.f / sum;
@@ -560,17 +586,30 @@ __global__ __launch_bounds__(256) void cva_attn_bwd_kernel(const CvaArgsT<AT> p)
     for (int j = 0; j < V; ++j) ds[i * V + j] = a[i * V + j] * (ds[i * V + j] - r) * p.scale;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < V * F; i += 256) {
-    const int vi = i / F, f = i - vi * F;
-    float dq = 0.f, dk = 0.f, dv = 0.f;
-    for (int j = 0; j < V; ++j) {
-      dq += ds[vi * V + j] * k[j * F + f];
-      dk += ds[j * V + vi] * q[j * F + f];
-      dv += a[j * V + vi] * d[j * F + f];
+  for (int f0 = 0; f0 < F; f0 += FC) {
+    const int fc = min(FC, F - f0);
+    if (!single) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < V * fc; i += 256) {
+        const int vi = i / fc, f = i - vi * fc;
+        q[i] = ldf(p.qkv + cva_off(p, b, vi, f0 + f, head, 0, 3 * p.R));
+        k[i] = ldf(p.qkv + cva_off(p, b, vi, f0 + f, head, 1, 3 * p.R));
+        d[i] = ldf(p.dout + cva_off(p, b, vi, f0 + f, head, 0, p.R));
+      }
+      __syncthreads();
     }
-    stf(p.dqkv + cva_off(p, b, vi, f, head, 0, 3 * p.R), dq);
-    stf(p.dqkv + cva_off(p, b, vi, f, head, 1, 3 * p.R), dk);
-    stf(p.dqkv + cva_off(p, b, vi, f, head, 2, 3 * p.R), dv);
+    for (int i = threadIdx.x; i < V * fc; i += 256) {
+      const int vi = i / fc, f = i - vi * fc;
+      float dq = 0.f, dk = 0.f, dv = 0.f;
+      for (int j = 0; j < V; ++j) {
+        dq += ds[vi * V + j] * k[j * fc + f];
+        dk += ds[j * V + vi] * q[j * fc + f];
+        dv += a[j * V + vi] * d[j * fc + f];
+      }
+      stf(p.dqkv + cva_off(p, b, vi, f0 + f, head, 0, 3 * p.R), dq);
+      stf(p.dqkv + cva_off(p, b, vi, f0 + f, head, 1, 3 * p.R), dk);
+      stf(p.dqkv + cva_off(p, b, vi, f0 + f, head, 2, 3 * p.R), dv);
+    }
   }
 }
 
@@ -1524,17 +1563,19 @@ extern "C" int sv_window_attention_bwd(const void* qkv, const float* table, cons
 
 static int cva_check(int B, int V, int P, int R, int heads) {
   SV_REQUIRE(B > 0 && V > 0 && V <= CVA_MAXV, "cross_view_attention: n_views=%d unsupported (max %d)", V, CVA_MAXV);
-  SV_REQUIRE(heads > 0 && R % heads == 0 && P * (R / heads) <= CVA_MAXF, "cross_view_attention: feature length %d exceeds %d",
-             P * (R / (heads > 0 ? heads : 1)), CVA_MAXF);
+  SV_REQUIRE(heads > 0 && R % heads == 0 && P > 0 && R / heads <= CVA_MAXF, "cross_view_attention: head_dim %d exceeds %d",
+             R / (heads > 0 ? heads : 1), CVA_MAXF);
   return SV_OK;
 }
+// features per chunk: whole positions, as many as the LDS arrays hold
+static int cva_chunk(int P, int R, int heads) { const int hd = R / heads; return min(P, CVA_MAXF / hd) * hd; }
 
 extern "C" int sv_cross_view_attention_fwd(const void* qkv, void* out, int B, int V, int P, int R, int heads, int act_dtype, void* stream) {
   SV_REQUIRE(qkv && out, "cross_view_attention_fwd: null argument");
   SV_REQUIRE_ACT(act_dtype);
   if (int rc = cva_check(B, V, P, R, heads)) return rc;
   SV_DISPATCH_ACT(act_dtype,
-    CvaArgsT<AT> a{static_cast<const AT*>(qkv), static_cast<AT*>(out), nullptr, nullptr, B, V, P, R, heads, R / heads, 1.0f / sqrtf((float)(R / heads) * (float)V)};
+    CvaArgsT<AT> a{static_cast<const AT*>(qkv), static_cast<AT*>(out), nullptr, nullptr, B, V, P, R, heads, R / heads, cva_chunk(P, R, heads), 1.0f / sqrtf((float)(R / heads) * (float)V)};
     hipLaunchKernelGGL(cva_attn_fwd_kernel<AT>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a););
   return check_launch("sv_cross_view_attention_fwd");
 }
@@ -1546,7 +1587,7 @@ extern "C" int sv_cross_view_attention_bwd(const void* qkv, const void* dout, vo
   if (int rc = cva_check(B, V, P, R, heads)) return rc;
   SV_DISPATCH_ACT(act_dtype,
     CvaArgsT<AT> a{static_cast<const AT*>(qkv), nullptr, static_cast<const AT*>(dout), static_cast<AT*>(dqkv), B, V, P, R, heads, R / heads,
-                   1.0f / sqrtf((float)(R / heads) * (float)V)};
+                   cva_chunk(P, R, heads), 1.0f / sqrtf((float)(R / heads) * (float)V)};
     hipLaunchKernelGGL(cva_attn_bwd_kernel<AT>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a););
   return check_launch("sv_cross_view_attention_bwd");
 }

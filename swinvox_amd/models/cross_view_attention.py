@@ -41,19 +41,28 @@ class CrossViewAttention(nn.Module):
     # ------------------------------------------------------------------------------------------------
     def cva_forward(self, x, B, V, training, stochastic, seeds):
         """x [B*V*49, C] (7x7 maps, channels last) -> same shape."""
-        if self.attention_spatial_downsample_ratio != 2:
-            raise NotImplementedError("swinvox_amd: ATT_SPATIAL_DOWNSAMPLE_RATIO must be 2 (7x7 -> 3x3), the reference default")
+        r = self.attention_spatial_downsample_ratio
+        if r not in (1, 2):
+            raise NotImplementedError("swinvox_amd: ATT_SPATIAL_DOWNSAMPLE_RATIO must be 1 (attention on the 7x7 grid) or 2 (7x7 -> 3x3, "
+                                      "the reference default); got %r" % (r,))
         C, R, I = self.in_channels, self.reduced_channels, B * V
-        dw = empty(I * 9, C, like=x)
-        call("sv_dwconv2x2_fwd", ptr(x), ptr(self.downsample_qkv.weight), ptr(self.downsample_qkv.bias), ptr(dw), I, C)
-        qkv = empty(I * 9, 3 * R, like=x)
-        ops.linear_fwd(dw, I * 9, self._s_qkv, self.qkv_conv.weight, qkv, bias=self.qkv_conv.bias)
-        att = empty(I * 9, R, like=x)
-        call("sv_cross_view_attention_fwd", ptr(qkv), ptr(att), B, V, 9, R, self.num_heads)
-        pr = empty(I * 9, C, like=x)
-        ops.linear_fwd(att, I * 9, self._s_proj, self.proj_conv.weight, pr, bias=self.proj_conv.bias)
+        P = 49 if r == 1 else 9                      # positions of the grid the attention runs on
+        if r == 1:                                   # reference cross_view_attention.py:67-73: no depth-wise down-sampling
+            dw = x
+        else:
+            dw = empty(I * 9, C, like=x)
+            call("sv_dwconv2x2_fwd", ptr(x), ptr(self.downsample_qkv.weight), ptr(self.downsample_qkv.bias), ptr(dw), I, C)
+        qkv = empty(I * P, 3 * R, like=x)
+        ops.linear_fwd(dw, I * P, self._s_qkv, self.qkv_conv.weight, qkv, bias=self.qkv_conv.bias)
+        att = empty(I * P, R, like=x)
+        call("sv_cross_view_attention_fwd", ptr(qkv), ptr(att), B, V, P, R, self.num_heads)
         up = empty(I * 49, C, like=x)
-        call("sv_upsample3to7_add_fwd", ptr(pr), ptr(x), C, ptr(up), I, C)
+        if r == 1:                                   # :110-120 without the interpolation: proj + x in the projection's epilogue
+            ops.linear_fwd(att, I * 49, self._s_proj, self.proj_conv.weight, up, bias=self.proj_conv.bias, residual=x, ldr=C)
+        else:
+            pr = empty(I * 9, C, like=x)
+            ops.linear_fwd(att, I * 9, self._s_proj, self.proj_conv.weight, pr, bias=self.proj_conv.bias)
+            call("sv_upsample3to7_add_fwd", ptr(pr), ptr(x), C, ptr(up), I, C)
         f1pre, f1 = empty(I * 49, C, like=x), empty(I * 49, C, like=x)
         ops.linear_fwd(up, I * 49, self._s_f0, self.ffn[0].weight, f1, bias=self.ffn[0].bias, act=ACT_GELU, pre_act=f1pre)
         st = BatchNormState(self.batch_norm, I * 49, training)
@@ -86,14 +95,23 @@ class CrossViewAttention(nn.Module):
         ops.linear_wgrad(df1, up, I * 49, self._s_f0, grads[self.ffn[0].weight], grads[self.ffn[0].bias])
         dup = empty(I * 49, C, like=x)
         ops.linear_dgrad(df1, I * 49, self._s_f0, self._s_f0.pack_dgrad(self.ffn[0].weight), dup)
-        dpr = empty(I * 9, C, like=x)
-        call("sv_upsample3to7_bwd", ptr(dup), ptr(dpr), I, C)
-        ops.linear_wgrad(dpr, att, I * 9, self._s_proj, grads[self.proj_conv.weight], grads[self.proj_conv.bias])
-        datt = empty(I * 9, R, like=x)
-        ops.linear_dgrad(dpr, I * 9, self._s_proj, self._s_proj.pack_dgrad(self.proj_conv.weight), datt)
-        dqkv = empty(I * 9, 3 * R, like=x)
-        call("sv_cross_view_attention_bwd", ptr(qkv), ptr(datt), ptr(dqkv), B, V, 9, R, self.num_heads)
-        ops.linear_wgrad(dqkv, dw, I * 9, self._s_qkv, grads[self.qkv_conv.weight], grads[self.qkv_conv.bias])
+        full = self.downsample_qkv is None             # ATT_SPATIAL_DOWNSAMPLE_RATIO = 1: attention on the 7x7 grid itself
+        P = 49 if full else 9
+        if full:
+            dpr = dup
+        else:
+            dpr = empty(I * 9, C, like=x)
+            call("sv_upsample3to7_bwd", ptr(dup), ptr(dpr), I, C)
+        ops.linear_wgrad(dpr, att, I * P, self._s_proj, grads[self.proj_conv.weight], grads[self.proj_conv.bias])
+        datt = empty(I * P, R, like=x)
+        ops.linear_dgrad(dpr, I * P, self._s_proj, self._s_proj.pack_dgrad(self.proj_conv.weight), datt)
+        dqkv = empty(I * P, 3 * R, like=x)
+        call("sv_cross_view_attention_bwd", ptr(qkv), ptr(datt), ptr(dqkv), B, V, P, R, self.num_heads)
+        ops.linear_wgrad(dqkv, dw, I * P, self._s_qkv, grads[self.qkv_conv.weight], grads[self.qkv_conv.bias])
+        if full:                                       # dx = qkv data gradient + the residual path, added in the epilogue
+            dx = empty(I * 49, C, like=x)
+            ops.linear_dgrad(dqkv, I * 49, self._s_qkv, self._s_qkv.pack_dgrad(self.qkv_conv.weight), dx, residual=dup, ldr=C)
+            return dx
         ddw = empty(I * 9, C, like=x)
         ops.linear_dgrad(dqkv, I * 9, self._s_qkv, self._s_qkv.pack_dgrad(self.qkv_conv.weight), ddw)
         dx = empty(I * 49, C, like=x)

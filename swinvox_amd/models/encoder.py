@@ -118,6 +118,9 @@ class Encoder(HipModule):
     def forward(self, rendering_images):
         assert rendering_images.dim() == 5 and rendering_images.shape[2] == 3, "expected [B, V, 3, H, W]"
         assert tuple(rendering_images.shape[-2:]) == (224, 224), "swinvox_amd: images must be 224x224 (reference cfg.CONST.IMG_H/W)"
+        if self.cross_view_attention is not None and rendering_images.shape[1] > 32:
+            raise RuntimeError("swinvox_amd: cross-view attention keeps all views of a sample in LDS: n_views must be <= 32 "
+                               f"(got {rendering_images.shape[1]}; the reference's data sets render 24)")
         return self._run(rendering_images)
 
     # ---- ResNet stem on the space-to-depth image --------------------------------------------------------

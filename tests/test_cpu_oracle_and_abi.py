@@ -38,7 +38,9 @@ def test_manifest_records_oracle_pins():
     pins = json.load(open(os.path.join(GOLD, "manifest.json")))["pins"]
     for k in ("decoder_eval_maxdiff", "merger_eval_maxdiff", "refiner_eval_maxdiff", "decoder_train_maxdiff",
               "cva_V1_maxdiff", "cva_V5_maxdiff", "tail_backward_rel_maxdiff", "encoder_plumbing_multi1_maxdiff",
-              "encoder_plumbing_multi0_maxdiff"):
+              "encoder_plumbing_multi0_maxdiff",
+              # ATT_SPATIAL_DOWNSAMPLE_RATIO = 1 and 2, forward + every gradient vs the reference module (make_cva_ratio_pin.py)
+              "cva_ds1_V1_fwd_bwd_maxdiff", "cva_ds1_V3_fwd_bwd_maxdiff", "cva_ds2_V1_fwd_bwd_maxdiff", "cva_ds2_V3_fwd_bwd_maxdiff"):
         assert pins[k] <= 1e-6, k
     for i in range(4):
         assert pins[f"swin_vs_hf_stage{i}_maxdiff"] < 1e-4 * max(1.0, pins[f"swin_vs_hf_stage{i}_absmax"])

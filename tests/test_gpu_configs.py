@@ -13,6 +13,7 @@ from swinvox_amd.models import Decoder, Encoder, Merger, Refiner  # noqa: E402
 
 from swinvox_amd.losses import bce_with_logits as bce  # noqa: E402  (sv_bce_logits behind an autograd node)
 CASES = [dict(B=2, V=1), dict(B=1, V=24), dict(B=3, V=5), dict(B=2, V=2, multi=False), dict(B=2, V=3, cva=False), dict(B=2, V=2, stages=[1, 3]),
+         dict(B=2, V=3, ds=1),                  # ATT_SPATIAL_DOWNSAMPLE_RATIO = 1: cross-view attention on the 7x7 grid (cross_view_attention.py:26-34,67-73)
          dict(B=1, V=2, stages=[0, 1, 2]),      # no stage 3: timm's FeatureListNet drops layers_3, so must the state_dict
          dict(B=1, V=2, variant="base")]        # Swin-B encoder (BASELINE config 5): embed 128, depths 2/2/18/2, heads 4/8/16/32
 
@@ -28,6 +29,8 @@ def test_config_variant_matches_the_oracle(dev, case):
             c.NETWORK.USE_CROSS_VIEW_ATTENTION = case["cva"]
         if "stages" in case:
             c.NETWORK.SWIN_T_STAGES = case["stages"]
+        if "ds" in case:
+            c.NETWORK.ATT_SPATIAL_DOWNSAMPLE_RATIO = case["ds"]
     torch.manual_seed(0)
     variant = case.get("variant", "tiny")
     onets = [O.Encoder(ocfg, variant=variant), O.Decoder(ocfg), O.Merger(ocfg), O.Refiner(ocfg)]
@@ -106,3 +109,62 @@ def test_swin_b_encoder_matches_the_golden_vector(dev):
     finally:
         S.set_math("f32")
     assert bool(torch.isfinite(f16).all()) and float((f16 - gold).abs().mean()) < 0.1 * float(gold.abs().mean()) + 1e-2
+
+
+def test_swin_b_encoder_with_fp8_attention(dev):
+    """BASELINE configuration 5 as a whole module: the Swin-B encoder (heads 4 / 8 / 16 / 32) with the window-attention forward's QK^T / PV
+    on fp8 (OCP e4m3) MFMA operands (`set_attention_fp8(True)`, bf16 everywhere else), eval forward against the committed fp32 golden
+    features of the Swin-B encoder, and one train-mode step (the backward keeps bf16 operands) for finite gradients on every parameter.
+    Stated bound: the fp8 features stay within 1.25x the bf16 path's own mean deviation from the golden vector (+ 1e-2 of mean|gold|) -
+    fp8 operands of the 49-key attention core must not add more than a quarter to what bf16 storage already costs on this weight set;
+    and they must differ from the bf16 result (the fp8 kernel really ran)."""
+    import json
+    import os
+    import numpy as np
+    from swinvox_amd import goldens, ops
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    case = json.load(open(os.path.join(gdir, "manifest.json")))["cases"]["swin_b_B1_V2"]
+    gold = torch.from_numpy(np.load(os.path.join(gdir, "case_swin_b_B1_V2.npz"))["features"])
+    enc = Encoder(S.default_cfg(), variant="base")
+    goldens.seeded_fill_(enc, case["weights_seed"])
+    enc.to(dev).eval()
+    x = goldens.synth_images(1, 2, case["seed"]).to(dev)
+    S.set_math("bf16")
+    S.set_storage("bf16")
+    try:
+        with torch.no_grad():
+            f16 = enc(x).cpu()
+            S.set_attention_fp8(True)
+            from swinvox_amd import hip as _hip
+            assert ops.attention_math() == _hip.MATH_FP8
+            f8 = enc(x).cpu()
+        enc.train()
+        enc.stochastic = False
+        enc.zero_grad(set_to_none=True)
+        enc(x).square().mean().backward()
+        grads_ok = all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in enc.parameters())
+    finally:
+        S.set_attention_fp8(False)
+        S.set_math("f32")
+    gm = float(gold.abs().mean())
+    e16, e8 = float((f16 - gold).abs().mean()), float((f8 - gold).abs().mean())
+    print(f"Swin-B encoder vs golden: mean|d| bf16 {e16:.4e}, bf16+fp8 attention {e8:.4e}, mean|gold| {gm:.4e}, fp8-vs-bf16 {float((f8 - f16).abs().mean()):.4e}")
+    assert bool(torch.isfinite(f8).all()) and grads_ok
+    assert float((f8 - f16).abs().max()) > 0.0
+    assert e8 <= 1.25 * e16 + 1e-2 * gm, (e8, e16, gm)
+
+
+def test_documented_refusals(dev):
+    """INTEGRATION.md section 3b, row by row: what the reference accepts and this library refuses must raise - never run something else."""
+    cfg = S.default_cfg()
+    cfg.NETWORK.ATT_SPATIAL_DOWNSAMPLE_RATIO = 3                      # 7 -> 2 -> 7 grid: not built (ratios 1 and 2 are)
+    enc = Encoder(cfg).to(dev).eval()
+    with pytest.raises(NotImplementedError, match="ATT_SPATIAL_DOWNSAMPLE_RATIO"), torch.no_grad():
+        enc(torch.zeros(1, 1, 3, 224, 224, device=dev))
+    enc = Encoder(S.default_cfg()).to(dev).eval()
+    with pytest.raises(AssertionError, match="224"), torch.no_grad():   # the reference resizes inside the Swin wrapper (swin_transformer.py:74-75)
+        enc(torch.zeros(1, 1, 3, 128, 128, device=dev))
+    with pytest.raises(RuntimeError, match="n_views"), torch.no_grad():  # cross-view attention keeps all views of a sample in LDS: V <= 32
+        enc(torch.zeros(1, 33, 3, 224, 224, device=dev))
+    with pytest.raises(RuntimeError, match="GPU"):                       # no CPU path
+        enc(torch.zeros(1, 1, 3, 224, 224))

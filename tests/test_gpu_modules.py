@@ -243,12 +243,14 @@ def test_bf16_end_to_end_at_the_headline_views(dev, nets):
     print("bf16 end-to-end V=8:", json.dumps(out))
     h, c = out["hip_bf16"], out["cpu_autocast_bf16"]
     assert bool(torch.isfinite(refined).all())
-    # the HIP bf16 path keeps fp32 islands (statistics, softmax, accumulators) the CPU autocast path does not: it must not be
-    # worse than 1.5x the CPU bf16 deviation (+ floors), and its IoU must stay within 2e-2 of the fp32 golden IoU
-    assert h["mean_abs_dlogit"] <= 1.5 * c["mean_abs_dlogit"] + 1e-2, out
-    assert h["max_abs_dlogit"] <= 1.5 * c["max_abs_dlogit"] + 5e-2, out
-    assert h["max_abs_dIoU"] <= max(2e-2, 1.5 * c["max_abs_dIoU"]), out
-    assert h["flips_outside_5e-2_band"] <= max(1.5 * c["flips_outside_5e-2_band"], 1e-3 * h["voxel_threshold_pairs"]), out
+    # north_star: IoU@32^3 within 1e-3 of the reference on fixed inputs - asserted as such for the benchmarked mode (measured 5-8e-4 over
+    # the boxes of rounds 2-3).  Logits: this weight set (seeded at default-init scale and calibrated, not trained) amplifies bf16 rounding
+    # through 12 Swin blocks for the HIP path and for CPU autocast alike, so they are bounded by the CPU-autocast deviation (1.2x + floors),
+    # and so are the occupancy flips outside the band.
+    assert h["max_abs_dIoU"] <= 1e-3, out
+    assert h["mean_abs_dlogit"] <= 1.2 * c["mean_abs_dlogit"] + 1e-2, out
+    assert h["max_abs_dlogit"] <= 1.2 * c["max_abs_dlogit"] + 5e-2, out
+    assert h["flips_outside_5e-2_band"] <= 1.2 * c["flips_outside_5e-2_band"], out
 
 
 def test_train_step_gradients_vs_oracle(dev, nets):

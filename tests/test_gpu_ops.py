@@ -481,7 +481,9 @@ def _ref_window_attention(qkv, table, I, H, C, heads, shift):
     return o.reshape(-1, C)
 
 
-@pytest.mark.parametrize("H,heads,shift", [(14, 3, 0), (14, 3, 3), (28, 6, 3), (7, 24, 0)])
+@pytest.mark.parametrize("H,heads,shift", [(14, 3, 0), (14, 3, 3), (28, 6, 3), (7, 24, 0),
+                                           # Swin-B head counts (BASELINE configuration 5: heads 4 / 8 / 16 / 32 at 56 / 28 / 14 / 7)
+                                           (56, 4, 3), (28, 8, 0), (28, 8, 3), (14, 16, 3), (7, 32, 0)])
 def test_window_attention(dev, H, heads, shift):
     g = torch.Generator().manual_seed(H + heads + shift)
     I, Cd = 2, heads * 32
@@ -514,10 +516,10 @@ def test_window_attention(dev, H, heads, shift):
     assert rel(dqkv16, qkv.grad) < 3e-2 and rel(dt16, table.grad) < 3e-2
 
 
-@pytest.mark.parametrize("V", [1, 3, 8])
-def test_cross_view_attention_core(dev, V):
-    g = torch.Generator().manual_seed(V)
-    B, P, R, heads = 2, 9, 128, 4
+@pytest.mark.parametrize("V,P", [(1, 9), (3, 9), (8, 9), (3, 49), (24, 49), (32, 9)])   # P = 49: ATT_SPATIAL_DOWNSAMPLE_RATIO = 1 (six feature chunks)
+def test_cross_view_attention_core(dev, V, P):
+    g = torch.Generator().manual_seed(V + P)
+    B, R, heads = 2, 128, 4
     qkv = torch.randn(B * V * P, 3 * R, generator=g, requires_grad=True)
     t = qkv.view(B, V, P, 3, heads, 32).permute(3, 0, 1, 4, 2, 5).reshape(3, B, V, heads, P * 32)
     s = torch.einsum("bihf,bjhf->bhij", t[0], t[1]) / math.sqrt(32 * V)
