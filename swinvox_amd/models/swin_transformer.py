@@ -267,6 +267,42 @@ def _attention_backward(blk, x, m1, r1, ln1, qkv, att, sc1, dx1, grads, I, H, W,
     return dx1
 
 
+def stage_forward(stage: SwinStage, x, I, training, stochastic, seeds, save=True):
+    """One backbone stage (timm SwinTransformerStage: PatchMerging at the START of stages 1-3, then the blocks): x [I*Hin*Hin, Cin]
+    -> ([I*res*res, dim], stage tape)."""
+    sctx = {"merge": None, "blocks": []}
+    if not isinstance(stage.downsample, nn.Identity):
+        ds = stage.downsample
+        Hin = stage.res * 2
+        Mo = I * stage.res * stage.res
+        lnm, mm, rm = ops.layernorm_fwd(x, ds.norm.weight, ds.norm.bias, Mo, 2 * stage.dim, merge_hw=(Hin, Hin))
+        y = empty(Mo, stage.dim, like=x)
+        ops.linear_fwd(lnm, Mo, ds.spec, ds.reduction.weight, y)
+        sctx["merge"] = (x, lnm, mm, rm, Mo, Hin)
+        x = y
+    for blk in stage.blocks:
+        x, bctx = block_forward(blk, x, I, training, stochastic, seeds, save)
+        sctx["blocks"].append(bctx)
+    return x, sctx
+
+
+def stage_backward(stage: SwinStage, sctx, dx, grads, I):
+    """dx [I*res*res, dim] (consumed) -> gradient wrt the stage input [I*Hin*Hin, Cin]; parameter gradients accumulate into `grads`."""
+    for blk, bctx in zip(reversed(list(stage.blocks)), reversed(sctx["blocks"])):
+        dx = block_backward(blk, bctx, dx, grads)
+    if sctx["merge"] is not None:
+        ds = stage.downsample
+        xin, lnm, mm, rm, Mo, Hin = sctx["merge"]
+        ops.linear_wgrad(dx, lnm, Mo, ds.spec, grads[ds.reduction.weight], None)
+        dln = empty(Mo, 2 * stage.dim, like=dx)
+        ops.linear_dgrad(dx, Mo, ds.spec, ds.spec.pack_dgrad(ds.reduction.weight), dln)
+        dxin = empty(I * Hin * Hin, stage.dim // 2, like=dx)
+        ops.layernorm_bwd(dln, xin, ds.norm.weight, mm, rm, dxin, grads[ds.norm.weight], grads[ds.norm.bias], Mo, 2 * stage.dim,
+                          merge_hw=(Hin, Hin))
+        dx = dxin
+    return dx
+
+
 def swin_forward(st: SwinTransformer, img_nhwc, I, training, stochastic, seeds, ready=None, save=True):
     """img_nhwc [I,224,224,3] -> list of stage-head outputs [I*HW, C] (NHWC rows) + tape.  `ready` (optional list) receives
     one event per head output, recorded on the current stream as soon as that output is complete, so that another stream
@@ -283,19 +319,7 @@ def swin_forward(st: SwinTransformer, img_nhwc, I, training, stochastic, seeds, 
     feats = []
     head_i = 0
     for si, stage in enumerate(bb.stages()):
-        sctx = {"merge": None, "blocks": []}
-        if not isinstance(stage.downsample, nn.Identity):
-            ds = stage.downsample
-            Hin = stage.res * 2
-            Mo = I * stage.res * stage.res
-            lnm, mm, rm = ops.layernorm_fwd(x, ds.norm.weight, ds.norm.bias, Mo, 2 * stage.dim, merge_hw=(Hin, Hin))
-            y = empty(Mo, stage.dim, like=x)
-            ops.linear_fwd(lnm, Mo, ds.spec, ds.reduction.weight, y)
-            sctx["merge"] = (x, lnm, mm, rm, Mo, Hin)
-            x = y
-        for blk in stage.blocks:
-            x, bctx = block_forward(blk, x, I, training, stochastic, seeds, save)
-            sctx["blocks"].append(bctx)
+        x, sctx = stage_forward(stage, x, I, training, stochastic, seeds, save)
         tape["stages"].append(sctx)
         if si in bb.out_indices:
             ln = st.layer_norm[head_i]
@@ -351,19 +375,7 @@ def swin_backward(st: SwinTransformer, tape, dfeats, I, grads, ready=None):
                 dx = dxe
             else:
                 call("sv_axpby", ptr(dx), ptr(dxe), ptr(dx), 1.0, 1.0, dx.numel())
-        sctx = tape["stages"][si]
-        for blk, bctx in zip(reversed(list(stage.blocks)), reversed(sctx["blocks"])):
-            dx = block_backward(blk, bctx, dx, grads)
-        if sctx["merge"] is not None:
-            ds = stage.downsample
-            xin, lnm, mm, rm, Mo, Hin = sctx["merge"]
-            ops.linear_wgrad(dx, lnm, Mo, ds.spec, grads[ds.reduction.weight], None)
-            dln = empty(Mo, 2 * stage.dim, like=dx)
-            ops.linear_dgrad(dx, Mo, ds.spec, ds.spec.pack_dgrad(ds.reduction.weight), dln)
-            dxin = empty(I * Hin * Hin, stage.dim // 2, like=dx)
-            ops.layernorm_bwd(dln, xin, ds.norm.weight, mm, rm, dxin, grads[ds.norm.weight], grads[ds.norm.bias], Mo, 2 * stage.dim,
-                              merge_hw=(Hin, Hin))
-            dx = dxin
+        dx = stage_backward(stage, tape["stages"][si], dx, grads, I)
     # patch embed: LN backward, then conv weight/bias gradient (the image itself needs no gradient)
     img, emb, pm, pr = tape["embed"]
     pe = bb.patch_embed

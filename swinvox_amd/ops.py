@@ -567,6 +567,9 @@ class BatchNormState:
              float(mom), float(bn.eps), 1 if self.training else 0, ptr(self.scale), ptr(self.shift), ptr(self.mean), ptr(self.rstd), self.C)
 
     def apply(self, x, ldx, y, ldy, act=ACT_NONE, slope=0.0, residual=None, ldr=0):
+        probe = _STATE.get("bn_probe")
+        if probe is not None:        # debug hook (tests): the producer's statistics next to the output it stored
+            probe(self, x, ldx)
         call("sv_scale_shift_act", ptr(x), ldx, ptr(self.scale), ptr(self.shift), ptr(residual), ldr, ptr(y), ldy, self.M, self.C, act, slope)
 
     def backward(self, dz, lddz, z, ldz, x, ldx, dx, lddx, dgamma, dbeta, act=ACT_NONE, slope=0.0, dres=None, lddres=0):
@@ -575,6 +578,13 @@ class BatchNormState:
         call("sv_bn_bwd", ptr(dz), lddz, ptr(z), ldz, ptr(x), ldx, ptr(self.bn.weight), ptr(self.mean), ptr(self.rstd), self.M, self.C,
              act, slope, 1 if self.training else 0, ptr(dx), lddx, ptr(dres), lddres, ptr(dgamma), ptr(dbeta), ptr(ws),
              ptr(self.scale), ptr(self.shift))
+
+
+def set_bn_probe(fn) -> None:
+    """Debug hook of the tests: fn(state, stored_output, ld) is called for every BatchNorm layer right before its normalisation pass,
+    when `state.sums` (the [BN_SLOTS][2C] double partial sums the producing kernel's epilogue accumulated) and the producer's stored
+    output are both complete on the current stream.  None removes it.  Process-wide configuration."""
+    _STATE["bn_probe"] = fn
 
 
 def transpose(src, dst, batch, R, Cc, lds=None, ldd=None, sb=None, db=None):

@@ -1,0 +1,169 @@
+"""Size-independent properties at the BENCHMARKED shape (B = 64 samples x V = 8 views = 512 images per GPU, bf16 MFMA operands + bf16
+activation storage) - every other parity test runs <= 24 images, while persistent tile schedulers, per-XCD counters, launch-slot
+images and split-K atomics all depend on the size.  (Round 2's worst bug, a tile computed twice by the wide GEMM's run-time tile
+scheduler, was invisible in the outputs and corrupted only the BatchNorm statistics - commit cadc99b.)
+
+ (i)   batch invariance: the eval-mode forward of 64 samples equals the same samples run as 32 batches of 2 (eval BatchNorm, no
+       dropout: nothing couples the samples), up to the bf16 rounding flips that different tile shapes cause;
+ (ii)  every BatchNorm producer of one training step: the statistics its epilogue accumulated equal the column sums of the output
+       it stored (all layers of all four modules, through a debug hook in ops.BatchNormState.apply);
+ (iii) two identical training steps (same seeds) give the same loss and the same parameter gradients up to the summation order of
+       float atomics (split-K weight gradients, statistics): <= 1e-5 L1-relative for every parameter.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import swinvox_amd as S  # noqa: E402
+from swinvox_amd import ops  # noqa: E402
+from swinvox_amd.helpers import init_weights  # noqa: E402
+from swinvox_amd.losses import bce_with_logits as bce  # noqa: E402
+from swinvox_amd.models import Decoder, Encoder, Merger, Refiner  # noqa: E402
+
+B, V = 64, 8
+
+
+@pytest.fixture(scope="module")
+def big(dev):
+    if torch.cuda.get_device_properties(dev).total_memory < 150 * 2 ** 30:
+        pytest.skip("needs the 288 GB of an MI355X")
+    from swinvox_amd import goldens
+    torch.manual_seed(1234)
+    cfg = S.default_cfg()
+    nets = [Encoder(cfg), Decoder(cfg), Merger(cfg), Refiner(cfg)]
+    for i, n in enumerate(nets):
+        goldens.seeded_fill_(n, 300 + i)          # default-scale weights: activations of O(1) in every layer (init_weights gives ~1e-10 logits)
+        n.to(dev)
+    g = torch.Generator().manual_seed(5)
+    images = (0.5 * torch.randn(B, V, 3, 224, 224, generator=g)).clamp(-1, 1).to(dev)
+    gt = (torch.rand(B, 32, 32, 32, generator=g) < 0.10).float().to(dev)
+    ops.set_math("bf16")
+    ops.set_storage("bf16")
+    # BatchNorm running statistics of the seeded fill are (0, 1): one train-mode pass over a few samples makes the eval forward well scaled
+    for n in nets:
+        n.train()
+    with torch.no_grad():
+        raw, vol = nets[1](nets[0](images[:4]))
+        nets[3](nets[2](raw, vol))
+    for n in nets:
+        for m in n.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.momentum = 1.0
+    with torch.no_grad():
+        raw, vol = nets[1](nets[0](images[:4]))
+        nets[3](nets[2](raw, vol))
+    for n in nets:
+        for m in n.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.momentum = 0.1
+    yield nets, images, gt
+    ops.set_math("f32")
+
+
+def _forward(nets, x):
+    f = nets[0](x)
+    raw, vol = nets[1](f)
+    merged = nets[2](raw, vol)
+    return f, vol, merged, nets[3](merged)
+
+
+def test_eval_forward_is_batch_invariant_at_the_bench_shape(dev, big):
+    nets, images, gt = big
+    for n in nets:
+        n.eval()
+    with torch.no_grad():
+        whole = [t.clone() for t in _forward(nets, images)]
+        parts = [[], [], [], []]
+        for b0 in range(0, B, 2):
+            for lst, t in zip(parts, _forward(nets, images[b0:b0 + 2])):
+                lst.append(t.clone())
+    names = ("features", "gen_volumes", "merged", "refined")
+    report = {}
+    for name, w, p in zip(names, whole, parts):
+        p = torch.cat(p, 0)
+        assert bool(torch.isfinite(w).all()) and w.shape == p.shape
+        d = (w - p).abs()
+        report[name] = (float(d.max() / (w.abs().max() + 1e-20)), float(d.mean() / (w.abs().mean() + 1e-20)))
+    print("batch invariance (max / mean relative difference):", report)
+    # a mis-scheduled tile (skipped, duplicated, written to the wrong rows) is an O(1) difference in at least one sample; different tile
+    # shapes between the two batch sizes only flip bf16 roundings of single elements, which this weight set amplifies to the figures below
+    for name, (mx, mean) in report.items():
+        assert mean < 2e-2 and mx < 0.25, (name, mx, mean)
+    # per sample: no sample may stand out (a wrong tile hits a few samples hard while the mean over 64 stays small)
+    w, p = whole[3], torch.cat(parts[3], 0)
+    per = (w - p).abs().flatten(1).mean(1) / (w.abs().flatten(1).mean(1) + 1e-20)
+    assert float(per.max()) < 5 * float(per.median()) + 1e-3, per
+
+
+def test_train_step_statistics_and_determinism_at_the_bench_shape(dev, big):
+    nets, images, gt = big
+    for n in nets:
+        n.train()
+    checked, bad = [], []
+
+    def probe(st, y, ld):
+        if not st.training:
+            return
+        C, M = st.C, st.M
+        k = st.sums.view(ops.BN_SLOTS, 2, C).sum(0)
+        rows = torch.as_strided(y, (M, C), (ld, 1), y.storage_offset())
+        s1 = torch.zeros(C, dtype=torch.float64, device=y.device)
+        s2, s4 = torch.zeros_like(s1), torch.zeros_like(s1)
+        for r0 in range(0, M, 1 << 20):
+            blk = rows[r0:r0 + (1 << 20)].double()
+            s1 += blk.sum(0)
+            blk = blk * blk
+            s2 += blk.sum(0)
+            s4 += (blk * blk).sum(0)
+        # The epilogue sums the fp32 accumulators, the tensor holds their bf16 roundings y = v (1 + d), |d| <= 2^-9, unbiased:
+        #   sum y^2 - sum v^2 ~ N(0, (2 * 2^-9 / sqrt 3)^2 * sum y^4),   sum y - sum v ~ N(0, (2^-9 / sqrt 3)^2 * sum y^2)
+        # 6 sigma of that per column is the tolerance.  A tile of 128 rows counted twice (or not at all) moves sum y^2 by 128 / M of
+        # itself: 20 ... 10^4 sigma for the layers of this model.
+        u = 2.0 ** -9 / math.sqrt(3.0)
+        sig2, sig1 = 2 * u * torch.sqrt(s4), u * torch.sqrt(s2)
+        z2 = float(((k[1] - s2).abs() / (sig2 + 1e-30 + 1e-9 * s2)).max())
+        z1 = float(((k[0] - s1).abs() / (sig1 + 1e-30 + 1e-9 * torch.sqrt(M * s2))).max())
+        dup = float((128.0 / M * s2 / (sig2 + 1e-30)).min())          # what one duplicated 128-row tile would read, in sigmas
+        checked.append((M, C, z1, z2, dup))
+        if not (z2 <= 6.0 and z1 <= 6.0):
+            bad.append((M, C, z1, z2))
+
+    def run(with_probe):
+        torch.manual_seed(77)                      # same dropout / drop-path seeds in both steps
+        for n in nets:
+            n.zero_grad(set_to_none=True)
+        ops.set_bn_probe(probe if with_probe else None)
+        try:
+            f, vol, merged, refined = _forward(nets, images)
+            total = bce(merged, gt) + bce(refined, gt)
+            total.backward()
+        finally:
+            ops.set_bn_probe(None)
+        torch.cuda.synchronize()
+        return float(total), [p.grad.clone() for n in nets for p in n.parameters()]
+
+    loss1, g1 = run(True)
+    # 43 ResNet + 6 neck + 1 cross-view attention + 4 fusion / conv blocks + 4 decoder + 6 merger + 5 refiner BatchNorm layers
+    assert len(checked) == 69, len(checked)
+    assert not bad, bad[:8]
+    print(f"BatchNorm producers checked: {len(checked)}; worst deviation {max(c[3] for c in checked):.2f} sigma (sum y^2), "
+          f"{max(c[2] for c in checked):.2f} sigma (sum y); a duplicated 128-row tile would read >= {min(c[4] for c in checked):.0f} sigma")
+    assert min(c[4] for c in checked) > 12.0       # the check has teeth in every layer
+    loss2, g2 = run(False)
+    assert math.isfinite(loss1) and abs(loss1 - loss2) <= 1e-6 * abs(loss1), (loss1, loss2)
+    names = [f"{type(n).__name__}.{k}" for n in nets for k, _ in n.named_parameters()]
+    worst, identical = (0.0, ""), 0
+    for k, a, b in zip(names, g1, g2):
+        assert bool(torch.isfinite(a).all()), k
+        den = float(a.abs().sum())
+        if den == 0.0:
+            assert float(b.abs().sum()) == 0.0, k
+            continue
+        e = float((a - b).abs().sum()) / den
+        identical += e == 0.0
+        worst = max(worst, (e, k))
+    print(f"two identical steps: {identical} of {len(names)} gradients bit-identical, worst L1-relative difference {worst[0]:.2e} at {worst[1]}")
+    assert worst[0] <= 1e-5, worst
