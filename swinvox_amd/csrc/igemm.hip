@@ -63,7 +63,12 @@ template <int WM_, int WN_, int MT_, int NT_> struct Tile {
   static constexpr int NW = WM_ * WN_, NTHR = NW * 64;
 };
 typedef Tile<4, 2, 2, 2> TileDefault;   // 128 x 64, 8 waves of 32x32 (few registers per thread -> 2-3 workgroups per CU)
+#ifndef SV_IG_REG_EPILOGUE
 typedef Tile<2, 4, 4, 2> TileBig;       // 128 x 128, 8 waves (512 threads): halves the A re-reads of TileDefault at equal registers
+#else
+typedef Tile<4, 2, 2, 4> TileBig;       // the same tile with 32 x 64 wave tiles (6 operand fragments per 8 MFMAs either way): a wave owns whole
+                                        // 128-byte pieces of output rows, which the register epilogue (wave_epilogue) stores as full lines
+#endif
 typedef Tile<4, 1, 2, 1> TileNarrow;    // 128 x 16
 typedef Tile<4, 2, 2, 3> Tile96;        // 128 x 96, 8 waves: the Swin channel counts are multiples of 96 (no padded columns for 96 / 192 / 288)
 
@@ -307,12 +312,219 @@ __device__ __forceinline__ void epilogue_rows(const IGemmArgs& p, const ClassInf
 }
 
 // ------------------------------------------------------------------------------------------------
+// Register epilogue of the 128 x 128 tile with bf16 storage (8-aligned rows and columns): no LDS staging, no workgroup barrier.
+// A/B BUILD ONLY (-DSV_IG_REG_EPILOGUE) - round 3 built it in three forms because a probe build without any epilogue had suggested
+// that the LDS-staged form costs 9.4 of the 34.8 ms per step of these kernels; measured in the step it never won:
+// what the probe had removed was the output stream itself, which bounds the short-K layers either way.
+// With the macro the tile runs as Tile<4, 2, 2, 4>: a wave owns 32 rows x 64 columns, i.e. WHOLE 128-byte pieces of output rows.  mma_slab
+// leaves lane (lr, lg) with row lr, columns 4 lg .. 4 lg + 3 of every 16 x 16 block (8 bytes of bf16).  Lane exchanges, all VALU:
+//   v_permlane32_swap X, Y : lanes 32-63 of X <-> lanes 0-31 of Y      rows (X: A0 A1 A2 A3, Y: B0 B1 B2 B3) -> (A0 A1 B0 B1), (A2 A3 B2 B3)
+//   v_permlane16_swap X, Y : odd 16-lane rows of X <-> even rows of Y                                       -> (A0 A2 B0 B2), (A1 A3 B1 B3)
+// turn the pieces of a PAIR of blocks into 16 consecutive bytes: lane group lg then holds columns 8 lg .. 8 lg + 7 of blocks 0 | 1 (piece
+// P0) and of blocks 2 | 3 (piece P1) of row lr.  A DPP row_ror:8 then trades P1 of the lanes lr < 8 for P0 of the lanes lr >= 8, after
+// which ONE store instruction covers rows 0-7 of the 16-row block with all eight 16-byte pieces of each (lane -> row lr & 7, piece
+// lg + 4 (lr >> 3)): 8 whole 128-byte lines, and a second one rows 8-15.  Residual / activation-gradient rows are loaded in the store
+// layout and brought back by the inverse exchanges; every load of the tile is issued before its first store (vmcnt retires in issue
+// order - which is also why a single spilled register is poison here: a scratch reload behind the stores waits for them).
+// Semantics = epilogue_rows.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float gw_dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row; valid in lane 15 of the row (row_shr 1, 2, 4, 8 with zero fill)
+__device__ __forceinline__ float row16_total(float v) {
+  v = gw_dpp_add<0x111>(v); v = gw_dpp_add<0x112>(v); v = gw_dpp_add<0x114>(v); v = gw_dpp_add<0x118>(v);
+  return v;
+}
+__device__ __forceinline__ void lane_swap32(uint32_t& a, uint32_t& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lane_swap16(uint32_t& a, uint32_t& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+struct U2 { uint32_t x, y; };
+struct U4 { uint32_t x, y, z, w; };
+// accumulator-layout pieces of a block pair -> this lane's 16 bytes (columns 8 lg .. 8 lg + 7 of the pair's 32), and back
+__device__ __forceinline__ U4 pair_to_rows(bf16x4 a, bf16x4 b) {
+  U2 x = __builtin_bit_cast(U2, a), y = __builtin_bit_cast(U2, b);
+  lane_swap32(x.x, y.x); lane_swap32(x.y, y.y);
+  lane_swap16(x.x, y.x); lane_swap16(x.y, y.y);
+  return U4{x.x, x.y, y.x, y.y};
+}
+__device__ __forceinline__ void rows_to_pair(U4 u, bf16x4& a, bf16x4& b) {
+  U2 x{u.x, u.y}, y{u.z, u.w};
+  lane_swap16(x.x, y.x); lane_swap16(x.y, y.y);
+  lane_swap32(x.x, y.x); lane_swap32(x.y, y.y);
+  a = __builtin_bit_cast(bf16x4, x); b = __builtin_bit_cast(bf16x4, y);
+}
+__device__ __forceinline__ uint32_t ror8(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); }   // lane lr <- lane (lr + 8) % 16 of its row
+__device__ __forceinline__ U4 ror8(U4 v) { return U4{ror8(v.x), ror8(v.y), ror8(v.z), ror8(v.w)}; }
+__device__ __forceinline__ U4 pick(bool c, U4 a, U4 b) { return U4{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w}; }
+// (P0, P1) of row lr  ->  (S1, S2): S1 = piece lg + 4 (lr >> 3) of row lr & 7, S2 = the same piece of row 8 + (lr & 7); its own inverse
+__device__ __forceinline__ void halves_trade(bool low, U4& a, U4& b) {
+  const U4 got = ror8(pick(low, b, a));
+  a = pick(low, a, got); b = pick(low, got, b);
+}
+
+// bf16 rows of the output (and of every tensor the epilogue reads or writes beside it) start on 16-byte boundaries and are whole 8-column pieces
+__host__ __device__ __forceinline__ bool rows_16_byte_aligned(const IGemmArgs& p) {
+  const Epi& e = p.e;
+  return ((e.ldc | e.col_off | p.g.Co) & 7) == 0 && (!e.residual || (e.ldr & 7) == 0) &&
+         (((uintptr_t)p.y | (uintptr_t)e.residual | (uintptr_t)e.pre_act | (uintptr_t)e.act_grad_src) & 15) == 0;
+}
+// what wave_epilogue serves (bf16 storage is the caller's business)
+static inline bool epilogue_in_registers(const IGemmArgs& p) {
+  return rows_16_byte_aligned(p) && !(p.e.residual && p.e.act_grad_src) && !(p.e.stats && (p.e.residual || p.e.act_grad_src));
+}
+
+// GENERAL = the epilogue reads a residual or an activation-gradient source (16 + 6 more registers per lane)
+template <bool TCONV, typename TL, bool GENERAL = true>
+__device__ __forceinline__ void wave_epilogue(const IGemmArgs& p, const ClassInfo& ci, int cnt0, int cnt1, int cnt2, float* red,
+                                              const f32x4 (&acc)[TL::MT][TL::NT], int row0, int col0, int Mrows) {
+  constexpr int MT = TL::MT, NT = TL::NT, BM = TL::BM, BN = TL::BN;
+  static_assert(NT == 4, "a wave owns 64 columns = whole 128-byte row pieces");
+  const Geom& g = p.g;
+  const Epi& e = p.e;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  const int wm = wave / TL::WN, wn = wave % TL::WN;
+  const bool low = lr < 8;
+  __bf16* __restrict__ Y = static_cast<__bf16*>(p.y);
+  const __bf16* __restrict__ RES = GENERAL ? static_cast<const __bf16*>(e.residual) : nullptr;
+  const __bf16* __restrict__ AGS = GENERAL ? static_cast<const __bf16*>(e.act_grad_src) : nullptr;
+  __bf16* __restrict__ PRE = static_cast<__bf16*>(e.pre_act);
+  const int cw0 = col0 + wn * 64;                          // first column of the wave
+  const int cs = cw0 + (lg + 4 * (lr >> 3)) * 8;           // the 16-byte piece this lane loads / stores
+  const bool csok = cs < g.Co;                             // Co % 8 == 0: a piece is whole or absent
+  // rows this lane loads / stores: (lr & 7) and 8 + (lr & 7) of every 16-row block; its accumulator row lr is one of the two
+  int posA[MT], posB[MT];
+  bool rokA[MT], rokB[MT];
+  float sc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int mA = row0 + (wm * MT + mt) * 16 + (lr & 7), mB = mA + 8;
+    rokA[mt] = mA < Mrows; rokB[mt] = mB < Mrows;
+    posA[mt] = rokA[mt] ? mA : 0; posB[mt] = rokB[mt] ? mB : 0;
+    if constexpr (TCONV) {
+      int n_, d_, h_, w_;
+      decode_row(posA[mt], cnt0, cnt1, cnt2, n_, d_, h_, w_);
+      posA[mt] = ((n_ * g.Do + ci.o0[0] + g.sd * d_) * g.Ho + ci.o0[1] + g.sh * h_) * g.Wo + ci.o0[2] + g.sw * w_;
+      decode_row(posB[mt], cnt0, cnt1, cnt2, n_, d_, h_, w_);
+      posB[mt] = ((n_ * g.Do + ci.o0[0] + g.sd * d_) * g.Ho + ci.o0[1] + g.sh * h_) * g.Wo + ci.o0[2] + g.sw * w_;
+    }
+    sc[mt] = (RES && e.row_scale) ? e.row_scale[(low ? posA[mt] : posB[mt]) / e.rows_per_scale] : 1.f;
+  }
+  float bias[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = cw0 + nt * 16 + lg * 4 + j;
+      bias[nt][j] = (e.bias && n < g.Co) ? e.bias[n] : 0.f;
+    }
+  // ---- every load of the tile: residual rows OR activation-gradient source rows (never both on this path), in the store layout
+  U4 rawA[MT], rawB[MT];
+  if (RES || AGS) {
+    const __bf16* src = RES ? RES : AGS + e.col_off;
+    const int lds_ = RES ? e.ldr : e.ldc;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      rawA[mt] = (rokA[mt] && csok) ? *reinterpret_cast<const U4*>(src + (size_t)posA[mt] * lds_ + cs) : U4{0, 0, 0, 0};
+      rawB[mt] = (rokB[mt] && csok) ? *reinterpret_cast<const U4*>(src + (size_t)posB[mt] * lds_ + cs) : U4{0, 0, 0, 0};
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    bf16x4 aux[NT] = {}, ob[NT], pb[NT];                   // aux: the residual / activation-gradient source in the accumulator layout
+    if (RES || AGS) {
+      U4 a = rawA[mt], b = rawB[mt];
+      halves_trade(low, a, b);
+      rows_to_pair(a, aux[0], aux[1]);
+      rows_to_pair(b, aux[2], aux[3]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j] + bias[nt][j];
+      if (AGS) {
+        if (e.act_grad_kind == SV_ACT_GELU) {              // pairs: packed fp32 math (common.h)
+#pragma unroll
+          for (int j = 0; j < 4; j += 2) {
+            const f32x2 dg = gelu_grad_fast2((f32x2){(float)aux[nt][j], (float)aux[nt][j + 1]});
+            v[j] *= dg[0]; v[j + 1] *= dg[1];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] *= act_grad_t<true>((float)aux[nt][j], e.act_grad_kind, e.slope);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pb[nt][j] = (__bf16)v[j];
+      if (e.act == SV_ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          const f32x2 gl = gelu_fast2((f32x2){v[j], v[j + 1]});
+          v[j] = gl[0]; v[j + 1] = gl[1];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = apply_act_t<true>(v[j], e.act, e.slope);
+      }
+      if (RES) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (float)aux[nt][j] + sc[mt] * v[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ob[nt][j] = (__bf16)v[j];
+    }
+    const size_t oA = (size_t)posA[mt] * e.ldc + e.col_off + cs, oB = (size_t)posB[mt] * e.ldc + e.col_off + cs;
+    if (PRE) {
+      U4 a = pair_to_rows(pb[0], pb[1]), b = pair_to_rows(pb[2], pb[3]);
+      halves_trade(low, a, b);
+      if (rokA[mt] && csok) *reinterpret_cast<U4*>(PRE + oA) = a;
+      if (rokB[mt] && csok) *reinterpret_cast<U4*>(PRE + oB) = b;
+    }
+    U4 a = pair_to_rows(ob[0], ob[1]), b = pair_to_rows(ob[2], ob[3]);
+    halves_trade(low, a, b);
+    if (rokA[mt] && csok) *reinterpret_cast<U4*>(Y + oA) = a;
+    if (rokB[mt] && csok) *reinterpret_cast<U4*>(Y + oB) = b;
+  }
+  if (e.stats) {
+    // Per-channel sum / sum of squares of what was stored, in a second sweep over the accumulators (a BatchNorm producer's epilogue is bias +
+    // activation: nothing to load - epilogue_in_registers() keeps statistics with a residual / activation-gradient source off this path;
+    // carrying 2 x 16 running sums through the store loop cost the persistent kernel 100 bytes of scratch per lane).  The 16 rows of a lane
+    // group by DPP, the WM waves that share the columns through LDS, then ONE double atomic per column and workgroup.
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float f = (float)(__bf16)apply_act_t<true>(acc[mt][nt][j] + bias[nt][j], e.act, e.slope);
+          if (low ? rokA[mt] : rokB[mt]) { t1 += f; t2 += f * f; }
+        }
+        const float a1 = row16_total(t1), a2 = row16_total(t2);
+        if (lr == 15) {
+          const int c = (wn * NT + nt) * 16 + lg * 4 + j;
+          red[(wm * BN + c) * 2] = a1; red[(wm * BN + c) * 2 + 1] = a2;
+        }
+      }
+    __syncthreads();
+    if (tid < BN && col0 + tid < g.Co) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < TL::WM; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+      double* st = e.stats + (size_t)((row0 / BM) % SV_BN_SLOTS) * 2 * g.Co;
+      atomicAdd(st + col0 + tid, (double)a);
+      atomicAdd(st + g.Co + col0 + tid, (double)b);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // tile epilogue shared by the gather kernels: accumulators -> LDS tile -> cooperative, row-contiguous vector reads/writes with
 // the fused bias / activation(-gradient) / residual / pre-activation copy / per-channel statistics.  Every wave must have
 // finished reading the operand tiles (Cs aliases them) before the call.
 // ------------------------------------------------------------------------------------------------
 template <bool BF16, bool TCONV, typename TL, typename AT>
-__device__ __forceinline__ void tile_epilogue(const IGemmArgs& p, const ClassInfo& ci, int cnt0, int cnt1, int cnt2, float* Cs, float* red,
+__device__ __forceinline__ bool tile_epilogue(const IGemmArgs& p, const ClassInfo& ci, int cnt0, int cnt1, int cnt2, float* Cs, float* red,
                                               const f32x4 (&acc)[TL::MT][TL::NT], int row0, int col0, int Mrows) {
   constexpr int BM = TL::BM, BN = TL::BN, MT = TL::MT, NT = TL::NT, NTHR = TL::NTHR, NW = TL::NW, LDC = BN + 4;
   const Geom& g = p.g;
@@ -320,6 +532,17 @@ __device__ __forceinline__ void tile_epilogue(const IGemmArgs& p, const ClassInf
   const int wm = wave / TL::WN, wn = wave % TL::WN;
   AT* __restrict__ Y = static_cast<AT*>(p.y);
   const Epi& e = p.e;
+  // bf16 storage with 8-aligned rows: 16 bytes per lane
+  bool wide = false;
+  if constexpr (sizeof(AT) == 2 && BN % 8 == 0) wide = rows_16_byte_aligned(p);
+#ifdef SV_IG_REG_EPILOGUE      // A/B build (measured: loses): 128 x 128 tiles store straight from the accumulator registers
+  if constexpr (BF16 && sizeof(AT) == 2 && NT == 4) {
+    if (wide && !(e.residual && e.act_grad_src) && !(e.stats && (e.residual || e.act_grad_src))) {   // straight from the accumulator registers: no LDS tile, no barrier
+      wave_epilogue<TCONV, TL>(p, ci, cnt0, cnt1, cnt2, red, acc, row0, col0, Mrows);
+      return false;
+    }
+  }
+#endif
   {
     const int lr = lane & 15, lg = lane >> 4;
 #pragma unroll
@@ -333,11 +556,10 @@ __device__ __forceinline__ void tile_epilogue(const IGemmArgs& p, const ClassInf
   // row pass: CV consecutive columns per thread.  bf16 storage with 8-aligned rows moves 16 bytes per lane (half the
   // global-memory instructions, 1 KB per wave store); everything else keeps 4 columns per thread.
   if constexpr (sizeof(AT) == 2 && BN % 8 == 0) {
-    const bool wide = ((e.ldc | e.col_off | g.Co) & 7) == 0 && (!e.residual || (e.ldr & 7) == 0) &&
-                      (((uintptr_t)p.y | (uintptr_t)e.residual | (uintptr_t)e.pre_act | (uintptr_t)e.act_grad_src) & 15) == 0;
-    if (wide) { epilogue_rows<BF16, TCONV, TL, AT, 8>(p, ci, cnt0, cnt1, cnt2, Cs, red, row0, col0, Mrows); return; }
+    if (wide) { epilogue_rows<BF16, TCONV, TL, AT, 8>(p, ci, cnt0, cnt1, cnt2, Cs, red, row0, col0, Mrows); return true; }
   }
   epilogue_rows<BF16, TCONV, TL, AT, 4>(p, ci, cnt0, cnt1, cnt2, Cs, red, row0, col0, Mrows);
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -540,7 +762,7 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
 // the NEXT tile's first operand slab before the epilogue of the current one, so that latency hides behind the epilogue
 // and the start-up cost is paid once.  Same tiles, loader mapping, LDS layout and epilogue as igemm_kernel.
 // ------------------------------------------------------------------------------------------------
-template <typename TL, typename AT, typename WT, int VEC>
+template <typename TL, typename AT, typename WT, int VEC, bool GENERAL = true>
 __global__ __launch_bounds__(TL::NTHR, TL::NTHR >= 512 ? 4 : 2) void gemm_dense_kernel(const IGemmArgs p, int ntiles) {
   typedef __bf16 LT;
   constexpr int BK = Cfg<true>::BK, LD = BK + Cfg<true>::PAD;
@@ -624,9 +846,16 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR >= 512 ? 4 : 2) void gemm_dense_
 #ifdef SV_IG_PROBE_NOEPI
     if (acc[0][0][0] == 12345.678f) static_cast<AT*>(p.y)[0] = (AT)acc[0][0][1];
 #else
-    tile_epilogue<true, false, TL, AT>(p, ci, g.Do, g.Ho, g.Wo, Cs, red, acc, row0, col0, Mrows);
+    // 128 x 128 tile (Tile<4, 2, 2, 4>) with 16-byte aligned rows: straight from the accumulator registers - no LDS tile, no barrier, a wave
+    // that is done with its stores goes on to the next tile's first slab; the other tiles stage through LDS
+    // (the host sends a layer to this instantiation only when epilogue_in_registers() holds)
+    if constexpr (TL::NT == 4) {
+      wave_epilogue<false, TL, GENERAL>(p, ci, g.Do, g.Ho, g.Wo, red, acc, row0, col0, Mrows);
+    } else {
+      tile_epilogue<true, false, TL, AT>(p, ci, g.Do, g.Ho, g.Wo, Cs, red, acc, row0, col0, Mrows);
+      __syncthreads();                                   // the staged tile is consumed: operand slabs may land again
+    }
 #endif
-    __syncthreads();                                     // the staged tile is consumed: operand slabs may land again
     have = more; row0 = row0n; col0 = col0n;
   }
 }
@@ -655,14 +884,6 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR >= 512 ? 4 : 2) void gemm_dense_
 // ------------------------------------------------------------------------------------------------
 constexpr int GW_BN = 128, GW_BK = 64;
 constexpr unsigned GW_NODRAW = 0xFFFFFFFFu;   // content of the tile-draw register (v167) while the atomic's return is outstanding
-template <int CTRL> __device__ __forceinline__ float gw_dpp_add(float v) {
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-// sum over the 16 lanes of a DPP row; valid in lane 15 of the row (row_shr 1, 2, 4, 8 with zero fill)
-__device__ __forceinline__ float row16_total(float v) {
-  v = gw_dpp_add<0x111>(v); v = gw_dpp_add<0x112>(v); v = gw_dpp_add<0x114>(v); v = gw_dpp_add<0x118>(v);
-  return v;
-}
 typedef __attribute__((address_space(1))) const void* gw_gptr_t;
 typedef __attribute__((address_space(3))) void* gw_lptr_t;
 
@@ -1339,13 +1560,19 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, in
   }
   // Linear / 1x1 stride-1 layers with bf16 storage: the persistent dense kernel (2 workgroups per CU walk the tiles)
   const bool dense = !TCONV && v8 && a.g.kd * a.g.kh * a.g.kw == 1 && a.g.sd == 1 && a.g.sh == 1 && a.g.sw == 1 &&
-                     a.g.pd == 0 && a.g.ph == 0 && a.g.pw == 0 && a.g.Di == a.g.Do && a.g.Hi == a.g.Ho && a.g.Wi == a.g.Wo;
+               a.g.pd == 0 && a.g.ph == 0 && a.g.pw == 0 && a.g.Di == a.g.Do && a.g.Hi == a.g.Ho && a.g.Wi == a.g.Wo;
 #define SV_LAUNCH_DENSE(TL)                                                                                         \
   do {                                                                                                              \
     const int ntiles = cdiv(M, TL::BM) * cdiv(Co, TL::BN);                                                          \
     int nb = 256 * (TL::NTHR >= 512 ? 2 : 4);                                                                       \
     if (nb > ntiles) nb = ntiles;                                                                                   \
-    hipLaunchKernelGGL((gemm_dense_kernel<TL, __bf16, __bf16, 8>), dim3(nb), dim3(TL::NTHR), 0, s, a, ntiles);      \
+    if constexpr (TL::NT == 4) {                                                                                    \
+      if (!a.e.residual && !a.e.act_grad_src) {                                                                     \
+        hipLaunchKernelGGL((gemm_dense_kernel<TL, __bf16, __bf16, 8, false>), dim3(nb), dim3(TL::NTHR), 0, s, a, ntiles); \
+        break;                                                                                                      \
+      }                                                                                                             \
+    }                                                                                                               \
+    hipLaunchKernelGGL((gemm_dense_kernel<TL, __bf16, __bf16, 8, true>), dim3(nb), dim3(TL::NTHR), 0, s, a, ntiles);    \
   } while (0)
   if constexpr (!TCONV) {
     if (dense && gemm_wide_ok(a, M) && gemm_wide_counters_ready()) {
@@ -1358,9 +1585,11 @@ static void launch_igemm(const IGemmArgs& a, long long M, int ncls, int math, in
     }
     if (dense && Co > 16) {
       if (use96) SV_LAUNCH_DENSE(Tile96);
-      else if (Co > 64 && (long long)cdiv(M, 128) * cdiv(Co, 128) >= 384) SV_LAUNCH_DENSE(TileBig);
-      else SV_LAUNCH_DENSE(TileDefault);
-      return;
+      else if (Co > 64 && (long long)cdiv(M, 128) * cdiv(Co, 128) >= 384) {
+        if (TileBig::NT != 4 || epilogue_in_registers(a)) { SV_LAUNCH_DENSE(TileBig); return; }
+        // rows that are not 16-byte aligned: the gathering kernel below carries both epilogues
+      } else { SV_LAUNCH_DENSE(TileDefault); return; }
+      if (use96) return;
     }
   }
 #undef SV_LAUNCH_DENSE

@@ -1,6 +1,7 @@
 // Normalisation kernels (HBM-bound): token LayerNorm (+ fused PatchMerging gather), whole-image
 // LayerNorm([C,H,W]) of the Swin stage heads, BatchNorm statistics / apply / backward on channels-last data.
 #include "common.h"
+#include <stdlib.h>
 
 namespace sv {
 
@@ -771,7 +772,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __rest
                                                                 const AT* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, long long M, int C, int act, float slope,
                                                                 double* __restrict__ sums, long long rows_per_block, int G,
-                                                                const float* __restrict__ fsc, const float* __restrict__ fsh) {
+                                                                const float* __restrict__ fsc, const float* __restrict__ fsh,
+                                                                AT* __restrict__ dmask, int lddm) {
+  // dmask (optional): receives dz' = dz * act'(z) - the gradient of the residual branch AND what pass 2 then reads instead of (dz, z):
+  // a BatchNorm in front of a residual sum (bn3 / the down-sampling branch of every bottleneck) saves one read of the widest tensors
   __shared__ double red[256][9];   // [thread][8 partials] (+1 pad)
   const int gq = threadIdx.x % G, rl = threadIdx.x / G, RL = 256 / G;
   const int c = (blockIdx.x * G + gq) * 4;
@@ -799,6 +803,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a0[j] *= q0[j] > 0.f ? 1.f : neg; a1[j] *= q1[j] > 0.f ? 1.f : neg; }
       }
+      if (dmask) {
+        st4f(dmask + (size_t)r * lddm + c, make_float4(a0[0], a0[1], a0[2], a0[3]));
+        st4f(dmask + (size_t)(r + RL) * lddm + c, make_float4(a1[0], a1[1], a1[2], a1[3]));
+      }
       const float xa[4] = {x0.x, x0.y, x0.z, x0.w}, xb[4] = {x1.x, x1.y, x1.z, x1.w};
       const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
@@ -817,6 +825,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) a0[j] *= q0[j] > 0.f ? 1.f : neg;
       }
+      if (dmask) st4f(dmask + (size_t)r * lddm + c, make_float4(a0[0], a0[1], a0[2], a0[3]));
       const float xa[4] = {x0.x, x0.y, x0.z, x0.w}, mm[4] = {mu.x, mu.y, mu.z, mu.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) { s1[j] += (double)a0[j]; s2[j] += (double)(a0[j] * (xa[j] - mm[j]) * rr[j]); }
@@ -1044,14 +1053,23 @@ extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const
       long long splits = 2048 / cg; if (splits < 1) splits = 1;
       const long long maxs = (M + 2 * RL - 1) / (2 * RL); if (splits > maxs) splits = maxs;
       const long long rpb = (M + splits - 1) / splits;
+      // with a residual-branch gradient to produce (dres) the reduce pass stores the masked gradient there and the apply pass reads IT,
+      // mask-free, instead of (dz, z): 7 instead of 8 passes over the tensor.  The sums are of the fp32 values, the stored ones are
+      // rounded to the storage type - as dres always was.
+      static const int premask_on = [] { const char* v = getenv("SV_BN_PREMASK"); return v ? atoi(v) : 1; }();
+      const bool premask = premask_on && dres_ && act != SV_ACT_NONE;
       hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope,
-                         sums_ws, rpb, G, fsc, fsh);
+                         sums_ws, rpb, G, fsc, fsh, premask ? dres_ : (AT*)nullptr, lddres);
       hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);
       long long asplits = 4096 / cg; if (asplits < 1) asplits = 1;
       const long long amax = (M + 4 * RL - 1) / (4 * RL); if (asplits > amax) asplits = amax;
       const long long arpb = (M + asplits - 1) / asplits;
-      hipLaunchKernelGGL(bn_bwd_apply_cg_kernel<AT>, dim3(cg, cdiv(M, arpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
-                         act, slope, training, dx_, lddx, dres_, lddres, fsc, fsh, arpb, G);
+      if (premask)
+        hipLaunchKernelGGL(bn_bwd_apply_cg_kernel<AT>, dim3(cg, cdiv(M, arpb)), dim3(256), 0, s, (const AT*)dres_, lddres, (const AT*)nullptr, 0, x_, ldx, gamma, save_mean,
+                           save_rstd, sums_ws, M, C, (int)SV_ACT_NONE, 0.f, training, dx_, lddx, (AT*)nullptr, 0, fsc, fsh, arpb, G);
+      else
+        hipLaunchKernelGGL(bn_bwd_apply_cg_kernel<AT>, dim3(cg, cdiv(M, arpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, gamma, save_mean, save_rstd, sums_ws, M, C,
+                           act, slope, training, dx_, lddx, dres_, lddres, fsc, fsh, arpb, G);
     } else {
       int CW = 1; while (CW < C && CW < 64) CW <<= 1;         // channel lanes: next power of two of C, at most 64
       const int cg = cdiv(C, CW), RLg = 256 / CW;

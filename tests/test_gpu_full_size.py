@@ -90,8 +90,9 @@ def test_eval_forward_is_batch_invariant_at_the_bench_shape(dev, big):
     print("batch invariance (max / mean relative difference):", report)
     # a mis-scheduled tile (skipped, duplicated, written to the wrong rows) is an O(1) difference in at least one sample; different tile
     # shapes between the two batch sizes only flip bf16 roundings of single elements, which this weight set amplifies to the figures below
+    # (measured: mean 2-5e-3, max 6-10e-3 of the tensor's mean / max)
     for name, (mx, mean) in report.items():
-        assert mean < 2e-2 and mx < 0.25, (name, mx, mean)
+        assert mean < 1e-2 and mx < 5e-2, (name, mx, mean)
     # per sample: no sample may stand out (a wrong tile hits a few samples hard while the mean over 64 stays small)
     w, p = whole[3], torch.cat(parts[3], 0)
     per = (w - p).abs().flatten(1).mean(1) / (w.abs().flatten(1).mean(1) + 1e-20)
@@ -118,11 +119,12 @@ def test_train_step_statistics_and_determinism_at_the_bench_shape(dev, big):
             blk = blk * blk
             s2 += blk.sum(0)
             s4 += (blk * blk).sum(0)
-        # The epilogue sums the fp32 accumulators, the tensor holds their bf16 roundings y = v (1 + d), |d| <= 2^-9, unbiased:
-        #   sum y^2 - sum v^2 ~ N(0, (2 * 2^-9 / sqrt 3)^2 * sum y^4),   sum y - sum v ~ N(0, (2^-9 / sqrt 3)^2 * sum y^2)
+        # The epilogue sums the fp32 accumulators, the tensor holds their bf16 roundings y = v (1 + d): |d| <= 2^-9 ... 2^-8 over a binade
+        # (half an ulp of an 8-bit significand), unbiased; with the upper figure
+        #   sum y^2 - sum v^2 ~ N(0, (2 * 2^-8 / sqrt 3)^2 * sum y^4),   sum y - sum v ~ N(0, (2^-8 / sqrt 3)^2 * sum y^2)
         # 6 sigma of that per column is the tolerance.  A tile of 128 rows counted twice (or not at all) moves sum y^2 by 128 / M of
-        # itself: 20 ... 10^4 sigma for the layers of this model.
-        u = 2.0 ** -9 / math.sqrt(3.0)
+        # itself: tens to 10^4 sigma for the layers of this model (asserted below).
+        u = 2.0 ** -8 / math.sqrt(3.0)
         sig2, sig1 = 2 * u * torch.sqrt(s4), u * torch.sqrt(s2)
         z2 = float(((k[1] - s2).abs() / (sig2 + 1e-30 + 1e-9 * s2)).max())
         z1 = float(((k[0] - s1).abs() / (sig1 + 1e-30 + 1e-9 * torch.sqrt(M * s2))).max())
@@ -151,7 +153,9 @@ def test_train_step_statistics_and_determinism_at_the_bench_shape(dev, big):
     assert not bad, bad[:8]
     print(f"BatchNorm producers checked: {len(checked)}; worst deviation {max(c[3] for c in checked):.2f} sigma (sum y^2), "
           f"{max(c[2] for c in checked):.2f} sigma (sum y); a duplicated 128-row tile would read >= {min(c[4] for c in checked):.0f} sigma")
-    assert min(c[4] for c in checked) > 12.0       # the check has teeth in every layer
+    # the check has teeth: in all but the few layers with the most rows (stem, 32^3 grids of the tail: M > 2M rows, whose kernels work in
+    # bricks of 512 voxels) ONE duplicated 128-row tile alone would exceed 10 sigma
+    assert sum(c[4] > 10.0 for c in checked) >= 55 and all(c[4] > 10.0 for c in checked if c[0] <= 2_000_000), sorted(c[4] for c in checked)[:12]
     loss2, g2 = run(False)
     assert math.isfinite(loss1) and abs(loss1 - loss2) <= 1e-6 * abs(loss1), (loss1, loss2)
     names = [f"{type(n).__name__}.{k}" for n in nets for k, _ in n.named_parameters()]
@@ -161,6 +165,11 @@ def test_train_step_statistics_and_determinism_at_the_bench_shape(dev, big):
         den = float(a.abs().sum())
         if den == 0.0:
             assert float(b.abs().sum()) == 0.0, k
+            continue
+        # analytically-zero gradients (a conv bias in front of a train-mode BatchNorm: the sum of the BatchNorm's input gradient) are
+        # rounding residue of the order 1e-7 of the layer's weight gradient - compared absolutely
+        if float(a.abs().max()) < 1e-5:
+            assert float((a - b).abs().max()) < 1e-6, k
             continue
         e = float((a - b).abs().sum()) / den
         identical += e == 0.0
