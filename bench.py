@@ -249,7 +249,7 @@ def main():
     #     timed region: per-kernel durations (events cannot be recorded inside a graph replay);
     # (2) once more on ONE stream: durations undisturbed by whatever runs beside the kernel -> the roofline figures.
     names = set(ENGINE) | {"sv_window_attention_fwd", "sv_window_attention_bwd", "sv_swin_mlp_fwd", "sv_swin_mlp_bwd", "sv_swin_mlp_wgrad",
-                               "sv_tconv4s2_fwd", "sv_swin_attn_block_fwd"}
+                               "sv_tconv4s2_fwd", "sv_swin_attn_block_fwd", "sv_swin_attn_block_bwd"}
     traced_steps = 2
     tracer = hip.Tracer(names) if rank == 0 else None
     eager_step()

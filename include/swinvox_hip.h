@@ -275,6 +275,17 @@ int sv_swin_attn_block_supported(int C, int heads, int act_dtype, int math);
 int sv_swin_attn_block_fwd(const void* x, const float* ln_g, const float* ln_b, const float* wqkv, const float* bqkv, const float* table,
                            const float* wproj, const float* bproj, const float* row_scale, void* x1, void* ln1, float* mean, float* rstd,
                            void* qkv, void* att, int I, int H, int W, int C, int heads, int shift, float eps, int act_dtype, void* stream);
+/* Fused BACKWARD of the same branch (data path): reads dx1 [M,96], the qkv rows and LayerNorm statistics the forward stored, and x; writes
+ * dqkv [M,288] (the engine's weight-gradient kernels read it: d qkv.weight / bias from (dqkv, ln1), d proj.weight / bias from (s dx1, att)) and
+ * dx = dx1 + LayerNormBackward(dqkv Wqkv) [M,96]; accumulates into dgamma / dbeta of norm1 [96] and dtable [169,3].  dbr (optional) receives
+ * s * dx1 when a drop-path scale is given (the projection's weight gradient needs it).  workspace: sv_window_attention_bwd_workspace_floats(3)
+ * floats, zero on entry.  9 passes over the token map instead of the 17 of sv_conv_gather -> sv_window_attention_bwd -> sv_conv_gather ->
+ * sv_layernorm_bwd.  Replaces the autograd of timm SwinTransformerBlock._attn + norm1 + DropPath behind reference models/swin_transformer.py:78
+ * (reference core/train.py:272). */
+int sv_swin_attn_block_bwd(const void* dx1, const void* qkv, const void* x, const float* mean, const float* rstd, const float* ln_g,
+                           const float* wqkv, const float* wproj, const float* table, const float* row_scale, void* dqkv, void* dx,
+                           void* dbr, float* dgamma, float* dbeta, float* dtable, float* workspace, int I, int H, int W, int C,
+                           int heads, int shift, int act_dtype, void* stream);
 
 /* Layout kernels of the ResNet stem (models/encoder.py:22: Conv2d(3, 64, 7, stride 2, pad 3) as a 4x4 / stride-1 convolution on the
  * space-to-depth image [I][112][112][(sy, sx, c) = 16]) and of the merger's stencil weights (merger.py:20-54):

@@ -1461,6 +1461,367 @@ __global__ __launch_bounds__(512, 1) void swin_attn_block_fwd_kernel(const Block
   }
 }
 
+
+// ---- fused BACKWARD of the attention branch of a stage-0 Swin block (C = 96, 3 heads) ------------------------------------------------
+// x1 = x + s * proj(window_attention(qkv(LayerNorm(x)))).  The unfused chain of this backward is four kernels over the token map - projection
+// data gradient, attention core backward, qkv data gradient, LayerNorm backward + residual - with datt, dqkv and dln1 going through HBM in
+// between: 17 passes over an [M, 96] tensor.  Here the data path is ONE kernel, 9 passes: it reads dx1, qkv (saved by the forward), x (+ the
+// saved LayerNorm statistics) and writes dqkv (the weight-gradient kernels of the engine need it in HBM) and dx.
+// One workgroup = 4 waves = one window at a time (49 tokens padded to 64; wave w owns token rows 16 w .. 16 w + 15 wherever rows are
+// owned); both weight matrices sit in LDS in DATA-GRADIENT orientation:
+//   P1  datt = (s dx1) Wproj          A rows = input channel j of proj, k = output channel   [96][96]
+//   P2  per head: the body of win_attn_bwd_wg_kernel (P recomputed) on the q | k | v columns of the window tile; dq / dk / dv leave for HBM
+//       as 16-byte row vectors and overwrite the head's q | k | v columns of the tile once every wave is done reading them
+//   P3  dln = dqkv Wqkv               A rows = input channel c of qkv, k = output column     [96][288]
+//   P4  LayerNorm backward + residual on the accumulators: dx = dx1 + rstd (g - mean(g) - xhat mean(g xhat)), g = dln gamma
+// Every product takes the weights as the FIRST MFMA operand with the row permutation of the forward kernel, so a lane's accumulators are
+// the 8 consecutive channels 32 ck + 8 lg .. + 7 of ONE token: every global access is a 16-byte vector in one layout (dx1, x, qkv, dqkv, dx),
+// and the LayerNorm row sums are 24 in-lane values + two lane-group exchanges.  dgamma / dbeta and the bias-table gradient stay in
+// registers over all windows of the workgroup.  The next window's dx1 and qkv rows are prefetched into registers during the current one.
+struct BlockBwdArgs {
+  const __bf16 *dx1, *qkv, *x; const float *mean, *rstd, *ln_g, *wqkv, *wproj, *table, *row_scale;
+  __bf16 *dqkv, *dx, *dbr; float *dgamma, *dbeta, *dt_ws;
+  int I, H, W, shift; float scale; int ntasks, tasks_per_group;
+};
+constexpr int BB_LDT = 296;   // bf16 row stride of the q | k | v (then dq | dk | dv) tile and of the qkv weight image: 592 bytes = 37 x 16
+constexpr int BB_LDD = 104;   // bf16 row stride of the s dx1 (then datt) tile and of the proj weight image: 208 bytes = 13 x 16
+constexpr int BB_SMEM = 96 * BB_LDT * 2 + 96 * BB_LDD * 2 + 64 * BB_LDT * 2 + 64 * BB_LDD * 2 + 2 * 64 * LDP_H * 2 + (3 * 176 * 2 + 96 + 2 * 96) * 4;
+
+__global__ __launch_bounds__(256, 1) void swin_attn_block_bwd_kernel(const BlockBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char bb_smem[BB_SMEM];
+  __bf16* Wq = reinterpret_cast<__bf16*>(bb_smem);          // [96][BB_LDT]  row R (permuted input channel c): Wqkv[k][c], k = 0 .. 287
+  __bf16* Wp = Wq + 96 * BB_LDT;                             // [96][BB_LDD]  row R (permuted input channel j): Wproj[i][j], i = 0 .. 95
+  __bf16* T = Wp + 96 * BB_LDD;                              // [64][BB_LDT]  scale q | k | v, then dq | dk | dv
+  __bf16* D = T + 64 * BB_LDT;                               // [64][BB_LDD]  s dx1, then datt
+  __bf16* Ps = D + 64 * BB_LDD;                              // [64][LDP_H]   P  [query][key]
+  __bf16* Ss = Ps + 64 * LDP_H;                              // [64][LDP_H]   dS [query][key]
+  float* bt = reinterpret_cast<float*>(Ss + 64 * LDP_H);     // [3][176] bias table per head
+  float* dbt = bt + 3 * 176;                                 // [3][176] its gradient (filled once, at the end)
+  float* lng = dbt + 3 * 176;                                // [96] norm1 weight
+  float* red = lng + 96;                                     // [2][96] dgamma / dbeta of the workgroup
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  // weight images, transposed from the native [out][in] layouts; LDS row R = 32 chunk + 16 half + ii <- channel 32 chunk + 8 (ii >> 2) + 4 half + (ii & 3)
+  for (int i = tid; i < 96 * 288; i += 256) {
+    const int R = i / 288, k = i - R * 288, ii = R & 15, c = (R & ~31) + 8 * (ii >> 2) + 4 * ((R >> 4) & 1) + (ii & 3);
+    Wq[R * BB_LDT + k] = (__bf16)p.wqkv[k * FB_C + c];
+  }
+  for (int i = tid; i < 96 * 96; i += 256) {
+    const int R = i / 96, k = i - R * 96, ii = R & 15, c = (R & ~31) + 8 * (ii >> 2) + 4 * ((R >> 4) & 1) + (ii & 3);
+    Wp[R * BB_LDD + k] = (__bf16)p.wproj[k * FB_C + c];
+  }
+  for (int i = tid; i < 3 * 176; i += 256) { const int h = i / 176, e = i - h * 176; bt[i] = e < 169 ? p.table[e * FB_HEADS + h] : 0.f; dbt[i] = 0.f; }
+  if (tid < 96) { lng[tid] = p.ln_g[tid]; red[tid] = 0.f; red[96 + tid] = 0.f; }
+  __syncthreads();
+
+  const int q = wave * 16 + lr;                      // the token of this lane wherever rows are owned (queries of P2, keys of its second half)
+  const bool qok = q < WT;
+  float bias[FB_HEADS][4][4];
+  {
+    const int qy = q / 7, qx = q - qy * 7;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = nt * 16 + lg * 4 + j, ky = key / 7, kx = key - ky * 7;
+#pragma unroll
+        for (int h = 0; h < FB_HEADS; ++h)
+          bias[h][nt][j] = key >= WT ? -1.0e30f : (qok ? bt[h * 176 + (qy - ky + 6) * 13 + (qx - kx + 6)] : 0.f);
+      }
+  }
+  const auto fmax2 = [](float a, float b) { return fmaxf(a, b); };
+  const auto fadd2 = [](float a, float b) { return a + b; };
+  const bf16x8 zero8 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+  f32x4 dsum[FB_HEADS][4];                           // bias-table gradient at this lane's (query, key) slots, over all windows
+#pragma unroll
+  for (int h = 0; h < FB_HEADS; ++h)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) dsum[h][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dgam[3][8], dbet[3][8];                      // LayerNorm parameter gradients of this lane's channels 32 ck + 8 lg + e, over all windows
+#pragma unroll
+  for (int ck = 0; ck < 3; ++ck)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dgam[ck][e] = 0.f; dbet[ck][e] = 0.f; }
+
+  const int nWx = p.W / 7, nW = (p.H / 7) * nWx;
+  const long long task0 = (long long)blockIdx.x * p.tasks_per_group;
+  TokMap tnext = task_map(task0 < p.ntasks ? task0 : 0, nW, nWx, p.H, p.W, p.shift);
+  const int qty = (qok ? q : 0) / 7, qtx = (qok ? q : 0) - qty * 7;
+  auto token_row = [&](const TokMap& t) -> size_t {
+    int ys = t.wy * 7 + qty + t.shift; if (ys >= t.H) ys -= t.H;
+    int xs = t.wx * 7 + qtx + t.shift; if (xs >= t.W) xs -= t.W;
+    return ((size_t)t.img * t.H + ys) * t.W + xs;
+  };
+  bf16x8 nd[3], nq[9];                               // the NEXT window's dx1 and qkv chunks of this lane's token
+  auto fetch = [&](bool in_range) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) nd[i] = zero8;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nq[i] = zero8;
+    if (in_range && qok) {
+      const size_t row = token_row(tnext);
+      const __bf16* sd = p.dx1 + row * FB_C + lg * 8;
+      const __bf16* sq = p.qkv + row * (3 * FB_C) + lg * 8;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) nd[i] = *reinterpret_cast<const bf16x8*>(sd + 32 * i);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) nq[i] = *reinterpret_cast<const bf16x8*>(sq + 32 * i);
+    }
+  };
+  fetch(task0 < p.ntasks);
+  for (int tt = 0; tt < p.tasks_per_group; ++tt) {
+    const long long task = task0 + tt;
+    if (task >= p.ntasks) break;                     // uniform over the workgroup
+    const TokMap tm = tnext;
+    const bool valid = qok;
+    const size_t row = token_row(tm);
+    bf16x8 dxr[3], xr[3];                            // dx1 (unscaled, for the residual) and x of this lane's token
+    const float sc = p.row_scale ? p.row_scale[tm.img] : 1.f;
+    float mean = 0.f, rstd = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { dxr[i] = nd[i]; xr[i] = zero8; }
+    if (valid) {
+      const __bf16* sx = p.x + row * FB_C + lg * 8;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) xr[i] = *reinterpret_cast<const bf16x8*>(sx + 32 * i);       // consumed in P4: lands during P1 - P3
+      mean = p.mean[row]; rstd = p.rstd[row];
+    }
+    __syncthreads();                                 // the previous window's tiles are consumed
+    // ---- tiles: s dx1 -> D, scale q | k | v -> T (q is rounded to bf16 AFTER the scale goes on, as the unfused core does with the q it reads)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)(sc * (float)dxr[i][e]);
+      *reinterpret_cast<bf16x8*>(D + q * BB_LDD + 32 * i + lg * 8) = o;
+      if (p.dbr && valid) *reinterpret_cast<bf16x8*>(p.dbr + row * FB_C + 32 * i + lg * 8) = o;   // for the projection's weight gradient
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      bf16x8 o = nq[i];
+      if (i < 3) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] * p.scale);
+      }
+      *reinterpret_cast<bf16x8*>(T + q * BB_LDT + 32 * i + lg * 8) = o;
+    }
+    if (++tnext.wx == nWx) { tnext.wx = 0; if (++tnext.wy == p.H / 7) { tnext.wy = 0; ++tnext.img; } }
+    fetch(tt + 1 < p.tasks_per_group && task + 1 < p.ntasks);
+    // ---- P1: datt = (s dx1) Wproj for this wave's 16 tokens (its own rows of D: no barrier), written back over them
+    {
+      bf16x8 df[3];
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) df[ks] = *reinterpret_cast<const bf16x8*>(D + q * BB_LDD + ks * 32 + lg * 8);
+#pragma unroll
+      for (int ck = 0; ck < 3; ++ck) {
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(Wp + (ck * 32 + hf * 16 + lr) * BB_LDD + ks * 32 + lg * 8);
+            acc[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, df[ks], acc[hf], 0, 0, 0);
+          }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[e >> 2][e & 3];
+        *reinterpret_cast<bf16x8*>(D + q * BB_LDD + ck * 32 + lg * 8) = o;
+      }
+    }
+    __syncthreads();                                 // every row of T and of D (= datt) is in LDS
+    const bool masked = p.shift > 0 && (tm.wy == p.H / 7 - 1 || tm.wx == nWx - 1);
+    unsigned kdiff = 0;                              // bit (nt * 4 + j): key in another region of the rolled map than the query
+    if (masked) {
+      const int qreg = qok ? tm.region(q) : 0;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = nt * 16 + lg * 4 + j;
+          if (qok && key < WT && tm.region(key) != qreg) kdiff |= 1u << (nt * 4 + j);
+        }
+    }
+    // ---- P2: attention backward, one head at a time (win_attn_bwd_wg_kernel's body on the tile columns of the head)
+#pragma unroll
+    for (int h = 0; h < FB_HEADS; ++h) {
+      const __bf16* Qs = T + h * HD;
+      const __bf16* Ks = T + FB_C + h * HD;
+      const __bf16* Vs = T + 2 * FB_C + h * HD;
+      const __bf16* Ds = D + h * HD;
+      f32x4 s[4], dp[4];
+      {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Qs + q * BB_LDT + lg * 8), c = *reinterpret_cast<const bf16x8*>(Ds + q * BB_LDD + lg * 8);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(Ks + (nt * 16 + lr) * BB_LDT + lg * 8);
+          const bf16x8 d = *reinterpret_cast<const bf16x8*>(Vs + (nt * 16 + lr) * BB_LDT + lg * 8);
+          s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d, c, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+      }
+      {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = s[nt][j] + bias[h][nt][j];
+            if (kdiff & (1u << (nt * 4 + j))) v += -100.0f;
+            s[nt][j] = v;
+            mx = fmaxf(mx, v);
+          }
+        mx = lanegroup_allreduce(mx, fmax2);
+        float sum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float e = __expf(s[nt][j] - mx); s[nt][j] = e; sum += e; }
+        const float inv = __builtin_amdgcn_rcpf(lanegroup_allreduce(sum, fadd2));
+        float r = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s[nt][j] *= inv; r += dp[nt][j] * s[nt][j]; }
+        r = lanegroup_allreduce(r, fadd2);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float dsv = s[nt][j] * (dp[nt][j] - r);
+            dp[nt][j] = dsv;
+            if (qok && nt * 16 + lg * 4 + j < WT) dsum[h][nt][j] += dsv;
+          }
+      }
+      bf16x8 dsf[2];                                 // dS of this query as the second operand of dQ = dS K
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        bf16x4 pb, sb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pb[j] = (__bf16)s[nt][j]; sb[j] = (__bf16)dp[nt][j]; dsf[nt >> 1][(nt & 1) * 4 + j] = sb[j]; }
+        *reinterpret_cast<bf16x4*>(Ps + q * LDP_H + nt * 16 + lg * 4) = pb;
+        *reinterpret_cast<bf16x4*>(Ss + q * LDP_H + nt * 16 + lg * 4) = sb;
+      }
+      f32x4 aq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};   // dQ = scale dS K: lane -> query lr, head channels 8 lg + 4 nt + j
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const __bf16* src = Ks + (2 * ks * 16 + lg * 4 + (lr >> 2)) * BB_LDT + (lr & 3) * 8 + nt * 4;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_a*)(src + 16 * BB_LDT));
+          const bf16x8 kT = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          aq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsf[ks], aq[nt], 0, 0, 0);
+        }
+      __syncthreads();                               // P and dS of all 64 queries are in LDS
+      f32x4 av[2], ak[2];                            // this wave's 16 KEYS: dV = P^T dO, dK = dS^T (scale Q)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) { av[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ak[nt] = av[nt]; }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pT = tr_frag(Ps, LDP_H, ks * 32, wave * 16, lane);
+        const bf16x8 sT = tr_frag(Ss, LDP_H, ks * 32, wave * 16, lane);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const bf16x8 bd = tr_frag_perm(Ds, BB_LDD, ks * 32, nt, lane);
+          const bf16x8 bq = tr_frag_perm(Qs, BB_LDT, ks * 32, nt, lane);
+          av[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bd, pT, av[nt], 0, 0, 0);
+          ak[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, sT, ak[nt], 0, 0, 0);
+        }
+      }
+      bf16x8 oq, ok_, ov;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { oq[e] = (__bf16)(aq[e >> 2][e & 3] * p.scale); ok_[e] = (__bf16)ak[e >> 2][e & 3]; ov[e] = (__bf16)av[e >> 2][e & 3]; }
+      if (valid) {
+        __bf16* dst = p.dqkv + row * (3 * FB_C) + h * HD + lg * 8;
+        *reinterpret_cast<bf16x8*>(dst) = oq;
+        *reinterpret_cast<bf16x8*>(dst + FB_C) = ok_;
+        *reinterpret_cast<bf16x8*>(dst + 2 * FB_C) = ov;
+      }
+      __syncthreads();                               // every wave is done with this head's q | k | v, P and dS
+      {
+        __bf16* dstl = T + q * BB_LDT + h * HD + lg * 8;     // this wave's own rows: dq | dk | dv become the operand of P3 (zero rows for the padding)
+        *reinterpret_cast<bf16x8*>(dstl) = valid ? oq : zero8;
+        *reinterpret_cast<bf16x8*>(dstl + FB_C) = valid ? ok_ : zero8;
+        *reinterpret_cast<bf16x8*>(dstl + 2 * FB_C) = valid ? ov : zero8;
+      }
+    }
+    // ---- P3: dln = dqkv Wqkv for this wave's 16 tokens (its own rows of T), P4: LayerNorm backward + residual on the accumulators
+    {
+      bf16x8 gf[9];
+#pragma unroll
+      for (int ks = 0; ks < 9; ++ks) gf[ks] = *reinterpret_cast<const bf16x8*>(T + q * BB_LDT + ks * 32 + lg * 8);
+      float dl[3][8], xh[3][8];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int ck = 0; ck < 3; ++ck) {
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 9; ++ks)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(Wq + (ck * 32 + hf * 16 + lr) * BB_LDT + ks * 32 + lg * 8);
+            acc[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, gf[ks], acc[hf], 0, 0, 0);
+          }
+        const float4 g0 = *reinterpret_cast<const float4*>(lng + ck * 32 + lg * 8), g1 = *reinterpret_cast<const float4*>(lng + ck * 32 + lg * 8 + 4);
+        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          // the unfused chain stores dln1 as bf16 between the qkv data gradient and the LayerNorm backward: the same rounding here
+          const float d = valid ? (float)(__bf16)acc[e >> 2][e & 3] : 0.f;
+          const float xv = valid ? ((float)xr[ck][e] - mean) * rstd : 0.f;
+          dbet[ck][e] += d; dgam[ck][e] += d * xv;
+          const float g = d * gm[e];
+          dl[ck][e] = g; xh[ck][e] = xv;
+          s1 += g; s2 += g * xv;
+        }
+      }
+      s1 = lanegroup_allreduce(s1, fadd2) * (1.f / FB_C);
+      s2 = lanegroup_allreduce(s2, fadd2) * (1.f / FB_C);
+      if (valid) {
+#pragma unroll
+        for (int ck = 0; ck < 3; ++ck) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)dxr[ck][e] + rstd * (dl[ck][e] - s1 - xh[ck][e] * s2));
+          *reinterpret_cast<bf16x8*>(p.dx + row * FB_C + ck * 32 + lg * 8) = o;
+        }
+      }
+    }
+  }
+  // ---- parameter gradients: registers -> LDS (once per workgroup) -> atomics
+  __syncthreads();
+#pragma unroll
+  for (int ck = 0; ck < 3; ++ck)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = group16_sum(dgam[ck][e]), b = group16_sum(dbet[ck][e]);      // the 16 tokens of a lane group
+      if (lr == 0) { atomicAdd(red + ck * 32 + lg * 8 + e, a); atomicAdd(red + 96 + ck * 32 + lg * 8 + e, b); }
+    }
+  if (qok) {
+    const int qy = q / 7, qx = q - qy * 7;
+#pragma unroll
+    for (int h = 0; h < FB_HEADS; ++h)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = nt * 16 + lg * 4 + j;
+          if (key < WT) {
+            const int ky = key / 7, kx = key - ky * 7;
+            atomicAdd(dbt + h * 176 + (qy - ky + 6) * 13 + (qx - kx + 6), dsum[h][nt][j]);
+          }
+        }
+  }
+  __syncthreads();
+  if (tid < 96) { atomicAdd(p.dgamma + tid, red[tid]); atomicAdd(p.dbeta + tid, red[96 + tid]); }
+  float* dst = p.dt_ws + (size_t)(blockIdx.x % ATTN_DT_SLOTS) * 169 * FB_HEADS;
+  for (int i = tid; i < 3 * 169; i += 256) {
+    const int h = i / 169, e = i - h * 169;
+    const float v = dbt[h * 176 + e];
+    if (v != 0.f) atomicAdd(dst + e * FB_HEADS + h, v);
+  }
+}
+
 }  // namespace sv
 
 using namespace sv;
@@ -1620,4 +1981,32 @@ extern "C" int sv_swin_attn_block_fwd(const void* x, const float* ln_g, const fl
   const int nblocks = cdiv(a.ntasks, 2 * a.tasks_per_group);
   hipLaunchKernelGGL(swin_attn_block_fwd_kernel, dim3(nblocks), dim3(512), 0, (hipStream_t)stream, a);
   return check_launch("sv_swin_attn_block_fwd");
+}
+
+/* Fused backward of the attention branch of a stage-0 block (see swin_attn_block_bwd_kernel).  dgamma / dbeta / dtable are accumulated into;
+ * workspace = sv_window_attention_bwd_workspace_floats(heads) floats, zero on entry. */
+extern "C" int sv_swin_attn_block_bwd(const void* dx1, const void* qkv, const void* x, const float* mean, const float* rstd, const float* ln_g,
+                                      const float* wqkv, const float* wproj, const float* table, const float* row_scale, void* dqkv, void* dx,
+                                      void* dbr, float* dgamma, float* dbeta, float* dtable, float* workspace, int I, int H, int W, int C,
+                                      int heads, int shift, int act_dtype, void* stream) {
+  SV_REQUIRE(dx1 && qkv && x && mean && rstd && ln_g && wqkv && wproj && table && dqkv && dx && dgamma && dbeta && dtable && workspace && I > 0,
+             "swin_attn_block_bwd: null/empty argument");
+  SV_REQUIRE(C == FB_C && heads == FB_HEADS && act_dtype == SV_BF16, "swin_attn_block_bwd: built for C = 96, 3 heads, bf16 token rows (got C=%d heads=%d dtype=%d)",
+             C, heads, act_dtype);
+  SV_REQUIRE(H % 7 == 0 && W % 7 == 0 && H >= 7 && W >= 7, "swin_attn_block_bwd: map %dx%d is not a multiple of the 7x7 window", H, W);
+  SV_REQUIRE(shift >= 0 && shift < 7 && (shift == 0 || (H > 7 && W > 7)), "swin_attn_block_bwd: bad shift %d for map %dx%d", shift, H, W);
+  SV_REQUIRE((((uintptr_t)dx1 | (uintptr_t)qkv | (uintptr_t)x | (uintptr_t)dqkv | (uintptr_t)dx | (uintptr_t)dbr) & 15) == 0,
+             "swin_attn_block_bwd: tensors must be 16-byte aligned");
+  BlockBwdArgs a{};
+  a.dx1 = static_cast<const __bf16*>(dx1); a.qkv = static_cast<const __bf16*>(qkv); a.x = static_cast<const __bf16*>(x);
+  a.mean = mean; a.rstd = rstd; a.ln_g = ln_g; a.wqkv = wqkv; a.wproj = wproj; a.table = table; a.row_scale = row_scale;
+  a.dqkv = static_cast<__bf16*>(dqkv); a.dx = static_cast<__bf16*>(dx); a.dbr = static_cast<__bf16*>(dbr);
+  a.dgamma = dgamma; a.dbeta = dbeta; a.dt_ws = workspace;
+  a.I = I; a.H = H; a.W = W; a.shift = shift; a.scale = 1.0f / sqrtf((float)HD);
+  a.ntasks = I * (H / 7) * (W / 7);
+  a.tasks_per_group = cdiv(a.ntasks, 256);                  // one workgroup per CU, every workgroup the same share of consecutive windows
+  const int nblocks = cdiv(a.ntasks, a.tasks_per_group);
+  hipLaunchKernelGGL(swin_attn_block_bwd_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_dtable_fold_kernel, dim3(cdiv(169 * heads, 256)), dim3(256), 0, (hipStream_t)stream, workspace, dtable, 169 * heads);
+  return check_launch("sv_swin_attn_block_bwd");
 }

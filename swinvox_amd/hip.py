@@ -52,7 +52,7 @@ _ACT_TYPED = {
     "sv_transpose", "sv_add_n", "sv_axpby", "sv_relu_bwd", "sv_maxpool2d_fwd", "sv_maxpool2d_bwd", "sv_avgpool2_fwd", "sv_avgpool2_bwd",
     "sv_decoder_seed_fwd", "sv_decoder_seed_bwd", "sv_maxpool3d_fwd", "sv_maxpool3d_bwd", "sv_dropout", "sv_rowscale",
     "sv_dwconv2x2_fwd", "sv_dwconv2x2_bwd", "sv_upsample3to7_add_fwd", "sv_upsample3to7_bwd", "sv_decoder_head_fwd", "sv_decoder_head_bwd",
-    "sv_merge_views_fwd", "sv_merge_views_bwd", "sv_stem_space_to_depth", "sv_swin_attn_block_fwd",
+    "sv_merge_views_fwd", "sv_merge_views_bwd", "sv_stem_space_to_depth", "sv_swin_attn_block_fwd", "sv_swin_attn_block_bwd",
 }
 # argument lists WITHOUT the act_dtype / stream tail (added in load())
 _PROTOS = {
@@ -97,6 +97,7 @@ _PROTOS = {
     "sv_swin_mlp_wgrad": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _F]),
     "sv_swin_attn_block_supported": (_I, None, [_I, _I, _I, _I]),
     "sv_swin_attn_block_fwd": (_I, [_P] * 15 + [_I, _I, _I, _I, _I, _I, _F]),
+    "sv_swin_attn_block_bwd": (_I, [_P] * 17 + [_I, _I, _I, _I, _I, _I]),
     "sv_cross_view_attention_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I]),
     "sv_cross_view_attention_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
     "sv_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _L]),

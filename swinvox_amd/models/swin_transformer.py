@@ -246,6 +246,22 @@ def _fused_mlp_backward(blk, x1, packs, sc2, dx2, grads, M, Cd, HW):
 
 def _attention_backward(blk, x, m1, r1, ln1, qkv, att, sc1, dx1, grads, I, H, W, Cd, M):
     """x1 = x + s1 * proj(attn(qkv(ln1))): dx1 is consumed (accumulator of the residual path); returns dx."""
+    esz = 2.0 if x.dtype == torch.bfloat16 else 4.0
+    if ops.fused_attn_block_bwd_enabled(Cd, blk.heads):
+        # data path in ONE kernel: dx1 -> projection data gradient -> attention backward (P recomputed) -> qkv data gradient -> LayerNorm
+        # backward + residual; dqkv goes to HBM for the weight gradients, which stay on the engine (weight-gradient stream)
+        a = blk.attn
+        dqkv, dx = empty(M, 3 * Cd, like=x), empty(M, Cd, like=x)
+        dbr = empty(M, Cd, like=x) if sc1 is not None else None
+        ws = ops.zeros_f64(8 * 169 * blk.heads, x.device)    # sv_window_attention_bwd_workspace_floats(heads) floats, zero on entry
+        ops.traced_call("sv_swin_attn_block_bwd", 2.0 * M * Cd * 4 * Cd + 10.0 * 49 * 32 * M * blk.heads, esz * M * Cd * (10 if sc1 is not None else 9),
+                        ptr(dx1), ptr(qkv), ptr(x), ptr(m1), ptr(r1), ptr(blk.norm1.weight), ptr(a.qkv.weight), ptr(a.proj.weight),
+                        ptr(a.relative_position_bias_table), ptr(sc1), ptr(dqkv), ptr(dx), ptr(dbr), ptr(grads[blk.norm1.weight]),
+                        ptr(grads[blk.norm1.bias]), ptr(grads[a.relative_position_bias_table]), ptr(ws), I, H, W, Cd, blk.heads, blk.shift,
+                        tag=f"M={M} C={Cd}")
+        ops.linear_wgrad(dbr if dbr is not None else dx1, att, M, blk.s_proj, grads[a.proj.weight], grads[a.proj.bias])
+        ops.linear_wgrad(dqkv, ln1, M, blk.s_qkv, grads[a.qkv.weight], grads[a.qkv.bias])
+        return dx
     # ---- attention branch: x1 = x + s1 * proj(attn(qkv(ln1)))
     dbr = dx1
     if sc1 is not None:
@@ -256,7 +272,7 @@ def _attention_backward(blk, x, m1, r1, ln1, qkv, att, sc1, dx1, grads, I, H, W,
     ops.linear_dgrad(dbr, M, blk.s_proj, blk.s_proj.pack_dgrad(blk.attn.proj.weight), datt)
     dqkv = empty(M, 3 * Cd, like=x)
     ws = ops.zeros_f64(8 * 169 * blk.heads, x.device)    # sv_window_attention_bwd_workspace_floats(heads) floats, zero on entry
-    esz = 2.0 if x.dtype == torch.bfloat16 else 4.0     # backward = 2.5 x the forward products (recomputed P, dP, dQ, dK, dV); bytes: qkv + dout in, dqkv out
+    # backward = 2.5 x the forward products (recomputed P, dP, dQ, dK, dV); bytes: qkv + dout in, dqkv out
     ops.traced_call("sv_window_attention_bwd", 10.0 * 49 * 32 * M * blk.heads, esz * 7 * M * Cd, ptr(qkv), ptr(blk.attn.relative_position_bias_table),
                     ptr(datt), ptr(dqkv), ptr(grads[blk.attn.relative_position_bias_table]), ptr(ws), I, H, W, Cd, blk.heads, blk.shift,
                     ops._STATE["math"], tag=f"M={M} C={Cd}")

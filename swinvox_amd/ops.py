@@ -489,6 +489,21 @@ def fused_attn_block_enabled(C: int, heads: int) -> bool:
             and hip.load().sv_swin_attn_block_supported(C, heads, hip.BF16, hip.MATH_BF16) == 1)
 
 
+def fused_attn_block_bwd_enabled(C: int, heads: int) -> bool:
+    """The fused BACKWARD of the attention branch (csrc/attn.hip swin_attn_block_bwd_kernel) serves the same blocks as the fused forward; it
+    reads what either forward stores (qkv, LayerNorm statistics), so fp8 attention in the forward does not switch it off.
+    A/B: SV_FUSED_ATTN_BWD=0 or set_fused_attn_block_bwd(False) route the branch through the unfused four-kernel chain."""
+    import os
+    if os.environ.get("SV_FUSED_ATTN_BWD", "1") == "0" or not _STATE.get("fused_attn_block_bwd", True):
+        return False
+    return (_STATE["math"] == hip.MATH_BF16 and _STATE["store"] == torch.bfloat16
+            and hip.load().sv_swin_attn_block_supported(C, heads, hip.BF16, hip.MATH_BF16) == 1)
+
+
+def set_fused_attn_block_bwd(on: bool) -> None:
+    _STATE["fused_attn_block_bwd"] = bool(on)
+
+
 def set_fused_attn_block(on: bool) -> None:
     """A/B switch: False routes the attention branch of every Swin block through the unfused LayerNorm / qkv / core / proj chain."""
     _STATE["fused_attn_block"] = bool(on)

@@ -125,6 +125,105 @@ def test_fused_attention_branch_matches_torch_and_the_unfused_chain(dev, I, H, s
         assert frac < 0.2, (k, frac)               # differing summation order flips the rounding of a minority of the elements
 
 
+def _reference_grads(p, I, H, shift, sc, dx1):
+    """fp64 autograd of the branch on the same (bf16-representable) inputs: gradients wrt x, norm1 weight / bias, the bias table, and the
+    gradient that reaches the qkv rows"""
+    from oracle.model import rel_pos_index, shift_attn_mask
+    x = p["x"].double().requires_grad_(True)
+    lg, lb = p["lg"].double().requires_grad_(True), p["lb"].double().requires_grad_(True)
+    table = p["table"].double().requires_grad_(True)
+    ln = torch.nn.functional.layer_norm(x, (C,), lg, lb, 1e-5)
+    qkv = ln @ p["wqkv"].double().T + p["bqkv"].double()
+    qkv.retain_grad()
+    t = qkv.view(I, H, H, 3 * C)
+    if shift:
+        t = torch.roll(t, (-shift, -shift), (1, 2))
+    tw = t.view(I, H // 7, 7, H // 7, 7, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 49, 3, HEADS, 32).permute(2, 0, 3, 1, 4)
+    q, k, v = tw[0] * 32 ** -0.5, tw[1], tw[2]
+    a = q @ k.transpose(-2, -1) + table[rel_pos_index(7).reshape(-1)].view(49, 49, HEADS).permute(2, 0, 1)[None]
+    if shift:
+        m = shift_attn_mask(H, H, 7, shift).double()
+        a = (a.view(I, -1, HEADS, 49, 49) + m[None, :, None]).view(-1, HEADS, 49, 49)
+    o = (a.softmax(-1) @ v).transpose(1, 2).reshape(-1, 49, C)
+    o = o.view(I, H // 7, H // 7, 7, 7, C).permute(0, 1, 3, 2, 4, 5).reshape(I, H, H, C)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    y = o.reshape(-1, C) @ p["wproj"].double().T + p["bproj"].double()
+    s = torch.ones(I, dtype=torch.float64) if sc is None else sc.double()
+    x1 = x + s.repeat_interleave(H * H)[:, None] * y
+    x1.backward(dx1.double())
+    return {"dx": x.grad.float(), "dqkv": qkv.grad.float(), "dgamma": lg.grad.float(), "dbeta": lb.grad.float(), "dtable": table.grad.float()}
+
+
+def _fused_bwd(d, fw, dx1, I, H, shift, scd):
+    dev = dx1.device
+    M = I * H * H
+    b16 = dict(dtype=torch.bfloat16, device=dev)
+    dqkv, dx = torch.empty(M, 3 * C, **b16), torch.empty(M, C, **b16)
+    dbr = torch.empty(M, C, **b16) if scd is not None else None
+    dg, db, dt = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(169, HEADS, device=dev)
+    ws = torch.zeros(int(hip.load().sv_window_attention_bwd_workspace_floats(HEADS)), device=dev)
+    call("sv_swin_attn_block_bwd", ptr(dx1), ptr(fw["qkv"]), ptr(d["x"]), ptr(fw["mean"]), ptr(fw["rstd"]), ptr(d["lg"]), ptr(d["wqkv"]), ptr(d["wproj"]),
+         ptr(d["table"]), ptr(scd), ptr(dqkv), ptr(dx), ptr(dbr), ptr(dg), ptr(db), ptr(dt), ptr(ws), I, H, H, C, HEADS, shift, act=hip.BF16)
+    torch.cuda.synchronize()
+    return {"dx": dx, "dqkv": dqkv, "dgamma": dg, "dbeta": db, "dtable": dt, "dbr": dbr}
+
+
+def _unfused_bwd(d, fw, dx1, I, H, shift, scd):
+    """the four-kernel data path of _attention_backward() when the fused backward is switched off"""
+    M = I * H * H
+    x = d["x"]
+    s_qkv, s_proj = ConvSpec.linear(C, 3 * C), ConvSpec.linear(C, C)
+    dx = dx1.clone()
+    dbr = dx
+    if scd is not None:
+        dbr = ops.empty(M, C, like=x)
+        call("sv_rowscale", ptr(dx), ptr(scd), ptr(dbr), M, C, H * H)
+    datt = ops.empty(M, C, like=x)
+    ops.linear_dgrad(dbr, M, s_proj, s_proj.pack_dgrad(d["wproj"]), datt)
+    dqkv = ops.empty(M, 3 * C, like=x)
+    dt = torch.zeros(169, HEADS, device=x.device)
+    ws = ops.zeros_f64(8 * 169 * HEADS, x.device)
+    call("sv_window_attention_bwd", ptr(fw["qkv"]), ptr(d["table"]), ptr(datt), ptr(dqkv), ptr(dt), ptr(ws), I, H, H, C, HEADS, shift, hip.MATH_BF16)
+    dln1 = ops.empty(M, C, like=x)
+    ops.linear_dgrad(dqkv, M, s_qkv, s_qkv.pack_dgrad(d["wqkv"]), dln1)
+    dg, db = torch.zeros(C, device=x.device), torch.zeros(C, device=x.device)
+    ops.layernorm_bwd(dln1, x, d["lg"], fw["mean"], fw["rstd"], dx, dg, db, M, C, accumulate_dx=True)
+    torch.cuda.synchronize()
+    return {"dx": dx, "dqkv": dqkv, "dgamma": dg, "dbeta": db, "dtable": dt}
+
+
+@pytest.mark.parametrize("I,H,shift,with_scale", [(2, 14, 0, False), (3, 14, 3, True), (1, 28, 3, False), (5, 7, 0, True), (40, 14, 3, True), (9, 56, 3, True)])
+def test_fused_attention_branch_backward(dev, I, H, shift, with_scale):
+    """sv_swin_attn_block_bwd (dx1 -> projection data gradient -> attention backward -> qkv data gradient -> LayerNorm backward + residual in
+    one kernel) against (a) fp64 autograd of the branch and (b) the unfused four-kernel chain on the same stored tensors: dx, dqkv, the
+    LayerNorm parameter gradients and the bias-table gradient."""
+    p = _case(I, H, 11 * I + H + shift)
+    sc = torch.tensor([0.0 if i % 3 == 1 else 1.0 / 0.9 for i in range(I)]) if with_scale else None
+    g = torch.Generator().manual_seed(I + H)
+    dx1_f = _bf(torch.randn(I * H * H, C, generator=g))
+    ref = _reference_grads(p, I, H, shift, sc, dx1_f)
+    d = {k: (v.to(torch.bfloat16) if k == "x" else v).to(dev).contiguous() for k, v in p.items()}
+    scd = sc.to(dev) if sc is not None else None
+    dx1 = dx1_f.to(torch.bfloat16).to(dev)
+    fw = _fused(d, I, H, shift, scd, side=True)
+    got = _fused_bwd(d, fw, dx1, I, H, shift, scd)
+    # (a) fp64 autograd: bf16 operands, bf16-stored qkv / dqkv / datt / dln1
+    for k, tol in (("dx", 2.5e-2), ("dqkv", 2.5e-2), ("dgamma", 2e-2), ("dbeta", 2e-2), ("dtable", 2e-2)):
+        assert _rel(got[k], ref[k]) < tol, (k, _rel(got[k], ref[k]))
+    if scd is not None:
+        assert torch.equal(got["dbr"].float(), (dx1.float() * scd.repeat_interleave(H * H)[:, None]).to(torch.bfloat16).float())
+    # (b) the unfused chain in bf16 math + bf16 storage
+    ops.set_math("bf16")
+    ops.set_storage("bf16")
+    try:
+        un = _unfused_bwd(d, fw, dx1, I, H, shift, scd)
+    finally:
+        ops.set_math("f32")
+    for k, tol in (("dx", 1.5e-2), ("dqkv", 1.5e-2), ("dgamma", 1e-2), ("dbeta", 1e-2), ("dtable", 1e-2)):
+        assert _rel(got[k], un[k]) < tol, (k, _rel(got[k], un[k]))
+
+
 def test_fused_attention_branch_rejects_bad_arguments(dev):
     z = torch.zeros(2 * 196, 96, dtype=torch.bfloat16, device=dev)
     f = torch.zeros(3 * 96 * 96, device=dev)
@@ -137,6 +236,11 @@ def test_fused_attention_branch_rejects_bad_arguments(dev):
         call("sv_swin_attn_block_fwd", *args, None, None, None, None, None, 2, 14, 14, 96, 3, 0, 1e-5, act=hip.F32)      # fp32 token rows
     with pytest.raises(RuntimeError, match="swin_attn_block"):
         call("sv_swin_attn_block_fwd", *args, None, None, None, None, None, 2, 15, 14, 96, 3, 0, 1e-5, act=hip.BF16)     # not a multiple of 7
+    bargs = [ptr(z)] * 3 + [ptr(f)] * 6 + [None, ptr(z), ptr(z), None, ptr(f), ptr(f), ptr(f), ptr(f)]
+    with pytest.raises(RuntimeError, match="swin_attn_block"):
+        call("sv_swin_attn_block_bwd", *bargs, 2, 14, 14, 192, 6, 0, act=hip.BF16)                                         # unsupported width
+    with pytest.raises(RuntimeError, match="swin_attn_block"):
+        call("sv_swin_attn_block_bwd", *bargs, 2, 14, 14, 96, 3, 0, act=hip.F32)                                           # fp32 token rows
 
 
 def test_encoder_step_with_and_without_the_fused_branch(dev):
@@ -157,7 +261,8 @@ def test_encoder_step_with_and_without_the_fused_branch(dev):
     try:
         for fused in (True, False):
             ops.set_fused_attn_block(fused)
-            assert ops.fused_attn_block_enabled(96, 3) == fused
+            ops.set_fused_attn_block_bwd(fused)
+            assert ops.fused_attn_block_enabled(96, 3) == fused and ops.fused_attn_block_bwd_enabled(96, 3) == fused
             for p in enc.parameters():
                 p.grad = None
             f = enc(x)
@@ -169,6 +274,7 @@ def test_encoder_step_with_and_without_the_fused_branch(dev):
             f_lean = enc(x).float().cpu()
     finally:
         ops.set_fused_attn_block(True)
+        ops.set_fused_attn_block_bwd(True)
         ops.set_math("f32")
     (fa, ga), (fb, gb) = res[True], res[False]
     assert torch.isfinite(fa).all() and _rel(fa, fb) < 3e-2, _rel(fa, fb)
