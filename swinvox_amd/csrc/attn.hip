@@ -1526,7 +1526,7 @@ __global__ __launch_bounds__(256, 1) void swin_attn_block_bwd_kernel(const Block
         const int key = nt * 16 + lg * 4 + j, ky = key / 7, kx = key - ky * 7;
 #pragma unroll
         for (int h = 0; h < FB_HEADS; ++h)
-          bias[h][nt][j] = key >= WT ? -1.0e30f : (qok ? bt[h * 176 + (qy - ky + 6) * 13 + (qx - kx + 6)] : 0.f);
+          bias[h][nt][j] = key >= WT ? -1.0e30f : (qok ? bt[h * 176 + (qy - ky + 6) * 13 + (qx - kx + 6)] * ATTN_LOG2E : 0.f);   // exp2 domain
       }
   }
   const auto fmax2 = [](float a, float b) { return fmaxf(a, b); };
@@ -1660,22 +1660,33 @@ __global__ __launch_bounds__(256, 1) void swin_attn_block_bwd_kernel(const Block
         }
       }
       {
+        // scores in the exp2 domain: log2 e rides on the bias (above) and on the raw product here (Q carries the plain softmax scale, as the
+        // dK product needs it)
         float mx = -3.0e38f;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float v = s[nt][j] + bias[h][nt][j];
-            if (kdiff & (1u << (nt * 4 + j))) v += -100.0f;
+            const float v = __builtin_fmaf(s[nt][j], ATTN_LOG2E, bias[h][nt][j]);
             s[nt][j] = v;
             mx = fmaxf(mx, v);
           }
+        if (masked) {                                // uniform over the workgroup: only windows on the rolled seam
+          mx = -3.0e38f;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (kdiff & (1u << (nt * 4 + j))) s[nt][j] += -100.0f * ATTN_LOG2E;
+              mx = fmaxf(mx, s[nt][j]);
+            }
+        }
         mx = lanegroup_allreduce(mx, fmax2);
         float sum = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { const float e = __expf(s[nt][j] - mx); s[nt][j] = e; sum += e; }
+          for (int j = 0; j < 4; ++j) { const float e = __builtin_amdgcn_exp2f(s[nt][j] - mx); s[nt][j] = e; sum += e; }
         const float inv = __builtin_amdgcn_rcpf(lanegroup_allreduce(sum, fadd2));
         float r = 0.f;
 #pragma unroll

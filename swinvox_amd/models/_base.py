@@ -149,11 +149,12 @@ class HipModule(nn.Module):
         hip.check_cuda(*inputs)
         hip.check_cuda(*self._param_list()[:1])
         for t in inputs:
-            if t.dtype != torch.float32:
+            # fp32, or the activation storage dtype (Decoder hands raw_features to Merger in it: no fp32 round trip of the largest tensor)
+            if t.dtype != torch.float32 and t.dtype != ops._STATE["store"]:
                 raise RuntimeError(f"swinvox_amd: expected float32 inputs, got {t.dtype}")
         params = self._param_list()
         save = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or any(t.requires_grad for t in inputs))
-        # module inputs / outputs are fp32; _fwd / _bwd convert to and from the activation storage dtype (ops.to_store / to_f32)
+        # module inputs / outputs are fp32 (exception: raw_features, see Decoder._fwd); _fwd / _bwd convert to and from the storage dtype
         return _ModuleFn.apply(self, len(inputs), save, *inputs, *params)
 
     def _seed(self) -> int:

@@ -77,7 +77,11 @@ class Decoder(HipModule):
         w5 = self.layer5[0]
         call("sv_decoder_head_fwd", ptr(x), ptr(w5.weight), ptr(w5.bias), ptr(raw12), ptr(vol), I * VOX)
         tape = (B, V, ctxs, x) if save else None
-        return (raw_view(ops.to_f32(raw12), B, V), ops.to_f32(vol)), tape
+        # raw_features [B,V,9,32,32,32] is by far the largest tensor that crosses a module boundary (9 x 32^3 values per view) and its only
+        # consumer is Merger: it is handed over in the activation storage dtype - under bf16 storage a bf16 tensor, as the reference's
+        # autocast region (core/train.py:235) returns half-precision module outputs too - which saves a bf16 -> fp32 -> bf16 round trip of
+        # 2.4 GB per step at B = 64 x V = 8 in the forward and the same for its gradient.  gen_volumes stays fp32.
+        return (raw_view(raw12, B, V), ops.to_f32(vol)), tape
 
     def _bwd(self, tape, grads, in_needs, draw, dvol):
         B, V, ctxs, x8 = tape

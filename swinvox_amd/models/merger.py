@@ -108,6 +108,7 @@ class Merger(HipModule):
     def _fwd(self, raw, vol, save):
         B, V = raw.shape[:2]
         M, tr, sl = B * V * VOX, self.training, self._slope
+        raw_dtype, vol_dtype = raw.dtype, vol.dtype
         x12 = ops.to_store(as_channels_last12(raw))
         vol = ops.to_store(vol)
         # the reference's torch.cat of the four 9-channel maps (merger.py:84) is never materialised: layers 1-4 write their
@@ -146,11 +147,11 @@ class Merger(HipModule):
         st6.apply(y6, 1, wl, 1, ACT_LRELU, sl)
         out = empty(B, 32, 32, 32, like=vol)
         call("sv_merge_views_fwd", ptr(wl), ptr(vol), ptr(out), B, V, VOX)
-        tape = (B, V, x12, vol, cat, ctx14, w5p, y5, st5, z5, y6, st6, wl, out) if save else None
+        tape = (B, V, x12, vol, cat, ctx14, w5p, y5, st5, z5, y6, st6, wl, out, raw_dtype, vol_dtype) if save else None
         return ops.to_f32(out), tape
 
     def _bwd(self, tape, grads, in_needs, dout):
-        B, V, x12, vol, cat, ctx14, w5p, y5, st5, z5, y6, st6, wl, out = tape
+        B, V, x12, vol, cat, ctx14, w5p, y5, st5, z5, y6, st6, wl, out, raw_dtype, vol_dtype = tape
         M, sl = B * V * VOX, self._slope
         dout = ops.to_store(dout)
         dwl = empty(M, 1, like=vol)
@@ -193,5 +194,6 @@ class Merger(HipModule):
             else:
                 dx = buf(M, 12, like=vol)
                 self._conv_dgrad(k, dy, 12, dx, 12, False)
-        draw = raw_view(ops.to_f32(dx), B, V) if in_needs[0] else None
-        return (draw, ops.to_f32(dvol) if in_needs[1] else None)
+        # gradients in the dtypes the inputs came in (raw_features arrives in the storage dtype from Decoder, fp32 from anyone else)
+        draw = raw_view(dx if raw_dtype == dx.dtype else ops.to_f32(dx), B, V) if in_needs[0] else None
+        return (draw, (dvol if vol_dtype == dvol.dtype else ops.to_f32(dvol)) if in_needs[1] else None)
