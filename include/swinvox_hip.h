@@ -191,6 +191,17 @@ int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const void* x, i
               const float* fwd_scale, const float* fwd_shift /* optional: with z == NULL the activation mask is recomputed as
               x*fwd_scale + fwd_shift > 0 (valid when the forward added no residual) - saves one tensor read per pass */,
               int act_dtype, void* stream);
+/* Activation mask as SIGN WORDS instead of the stored output (BatchNorm in front of a residual sum: bn3 and the down-sampling branch of every
+ * bottleneck, reference models/encoder.py:22-23): sv_scale_shift_act_signs also writes, per row and per 256 channels, four 64-bit words - bit l of
+ * word j = (value of channel 256 b + 4 l + j before the activation) > 0 - i.e. [M][C/64] uint64, 1/16 of the bytes of a bf16 output;
+ * sv_bn_bwd_signs takes its mask from them (and always returns the masked gradient dz * act' through dres, which its second pass reads back
+ * instead of (dz, z)).  C % 256 == 0 (sv_bn_signs_supported), rows 4-aligned. */
+int sv_bn_signs_supported(int C);
+int sv_scale_shift_act_signs(const void* x, int ldx, const float* scale, const float* shift, const void* residual, int ldr, void* y, int ldy,
+                             long long M, int C, int act, float slope, void* signs, int act_dtype, void* stream);
+int sv_bn_bwd_signs(const void* dz, int lddz, const void* signs, const void* x, int ldx, const float* gamma, const float* save_mean,
+                    const float* save_rstd, long long M, int C, int act, float slope, int training, void* dx, int lddx, void* dres, int lddres,
+                    float* dgamma, float* dbeta, double* sums_ws, int act_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention cores.  Window attention = timm WindowAttention + SwinTransformerBlock roll/partition/mask

@@ -694,7 +694,10 @@ template <typename AT>
 __global__ __launch_bounds__(256) void scale_shift_act_cg_kernel(const AT* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, const AT* __restrict__ res, int ldr,
                                                                  AT* __restrict__ y, int ldy, long long M, int C, int act, float slope,
-                                                                 long long rows_per_block, int G) {
+                                                                 long long rows_per_block, int G, unsigned long long* __restrict__ signs) {
+  // signs (optional; G == 64 and C % 256 == 0, so that a wave is the 64 column groups of ONE row): bit `lane` of word
+  // signs[(row * (C / 256) + blockIdx.x) * 4 + j] = (value of channel 256 blockIdx.x + 4 lane + j before the activation) > 0 - the
+  // activation mask the backward needs, 1/16 of the bytes of the output it would otherwise re-read
   const int gq = threadIdx.x % G, rl = threadIdx.x / G, RL = 256 / G;
   const int c = (blockIdx.x * G + gq) * 4;
   if (c >= C || rl >= RL) return;
@@ -708,6 +711,15 @@ __global__ __launch_bounds__(256) void scale_shift_act_cg_kernel(const AT* __res
     if (res) {
       const float4 rv = ld4f(res + (size_t)r * ldr + c);
       o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+    }
+    if (signs) {
+      const unsigned long long b0 = __builtin_amdgcn_ballot_w64(o[0] > 0.f), b1 = __builtin_amdgcn_ballot_w64(o[1] > 0.f);
+      const unsigned long long b2 = __builtin_amdgcn_ballot_w64(o[2] > 0.f), b3 = __builtin_amdgcn_ballot_w64(o[3] > 0.f);
+      if (gq == 0) {
+        unsigned long long* w = signs + ((size_t)r * (C >> 8) + blockIdx.x) * 4;
+        *reinterpret_cast<ulonglong2*>(w) = make_ulonglong2(b0, b1);
+        *reinterpret_cast<ulonglong2*>(w + 2) = make_ulonglong2(b2, b3);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j], act, slope);
@@ -773,7 +785,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __rest
                                                                 const float* __restrict__ rstd, long long M, int C, int act, float slope,
                                                                 double* __restrict__ sums, long long rows_per_block, int G,
                                                                 const float* __restrict__ fsc, const float* __restrict__ fsh,
-                                                                AT* __restrict__ dmask, int lddm) {
+                                                                AT* __restrict__ dmask, int lddm, const unsigned long long* __restrict__ signs) {
+  // signs (optional, instead of z; G == 64, C % 256 == 0): the forward's activation mask, one bit per element (scale_shift_act_cg_kernel)
   // dmask (optional): receives dz' = dz * act'(z) - the gradient of the residual branch AND what pass 2 then reads instead of (dz, z):
   // a BatchNorm in front of a residual sum (bn3 / the down-sampling branch of every bottleneck) saves one read of the widest tensors
   __shared__ double red[256][9];   // [thread][8 partials] (+1 pad)
@@ -785,14 +798,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __rest
   if (c < C && rl < RL) {
     const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
     float4 msc = make_float4(0.f, 0.f, 0.f, 0.f), msh = msc;          // no saved output: the mask is recomputed from x
-    if (!z && act != SV_ACT_NONE) { msc = *reinterpret_cast<const float4*>(fsc + c); msh = *reinterpret_cast<const float4*>(fsh + c); }
+    if (!z && !signs && act != SV_ACT_NONE) { msc = *reinterpret_cast<const float4*>(fsc + c); msh = *reinterpret_cast<const float4*>(fsh + c); }
     const float neg = act == SV_ACT_LRELU ? slope : 0.f;
     long long r = r0 + rl;
     for (; r + RL < r1e; r += 2 * RL) {   // two rows in flight
       const float4 d0 = ld4f(dz + (size_t)r * lddz + c), d1 = ld4f(dz + (size_t)(r + RL) * lddz + c);
       const float4 x0 = ld4f(x + (size_t)r * ldx + c), x1 = ld4f(x + (size_t)(r + RL) * ldx + c);
       float a0[4] = {d0.x, d0.y, d0.z, d0.w}, a1[4] = {d1.x, d1.y, d1.z, d1.w};
-      if (act != SV_ACT_NONE) {
+      if (act != SV_ACT_NONE && signs) {
+        const ulonglong2* w0 = reinterpret_cast<const ulonglong2*>(signs + ((size_t)r * (C >> 8) + blockIdx.x) * 4);
+        const ulonglong2* w1 = reinterpret_cast<const ulonglong2*>(signs + ((size_t)(r + RL) * (C >> 8) + blockIdx.x) * 4);
+        const ulonglong2 p0 = w0[0], p1 = w0[1], q0 = w1[0], q1 = w1[1];       // the same four words for the whole wave (one row each)
+        const unsigned long long m0[4] = {p0.x, p0.y, p1.x, p1.y}, m1[4] = {q0.x, q0.y, q1.x, q1.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a0[j] *= ((m0[j] >> gq) & 1ull) ? 1.f : neg; a1[j] *= ((m1[j] >> gq) & 1ull) ? 1.f : neg; }
+      } else if (act != SV_ACT_NONE) {
         float4 z0, z1;
         if (z) { z0 = ld4f(z + (size_t)r * ldz + c); z1 = ld4f(z + (size_t)(r + RL) * ldz + c); }
         else {
@@ -818,7 +838,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __rest
     for (; r < r1e; r += RL) {
       const float4 d0 = ld4f(dz + (size_t)r * lddz + c), x0 = ld4f(x + (size_t)r * ldx + c);
       float a0[4] = {d0.x, d0.y, d0.z, d0.w};
-      if (act != SV_ACT_NONE) {
+      if (act != SV_ACT_NONE && signs) {
+        const ulonglong2* w0 = reinterpret_cast<const ulonglong2*>(signs + ((size_t)r * (C >> 8) + blockIdx.x) * 4);
+        const ulonglong2 p0 = w0[0], p1 = w0[1];
+        const unsigned long long m0[4] = {p0.x, p0.y, p1.x, p1.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a0[j] *= ((m0[j] >> gq) & 1ull) ? 1.f : neg;
+      } else if (act != SV_ACT_NONE) {
         const float4 z0 = z ? ld4f(z + (size_t)r * ldz + c)
                             : make_float4(__fmaf_rn(x0.x, msc.x, msh.x), __fmaf_rn(x0.y, msc.y, msh.y), __fmaf_rn(x0.z, msc.z, msh.z), __fmaf_rn(x0.w, msc.w, msh.w));
         const float q0[4] = {z0.x, z0.y, z0.z, z0.w};
@@ -990,8 +1016,11 @@ static inline bool aligned4(int act_dtype, const void* a, const void* b = nullpt
   return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e) & m) == 0;
 }
 
-extern "C" int sv_scale_shift_act(const void* x, int ldx, const float* scale, const float* shift, const void* residual, int ldr,
-                                  void* y, int ldy, long long M, int C, int act, float slope, int act_dtype, void* stream) {
+// sign words of sv_scale_shift_act_signs / sv_bn_bwd_signs need the wave-per-row mapping of the vector kernels: G == 64 column groups
+static inline bool bn_signs_ok(int C) { return C % 256 == 0; }
+
+static int scale_shift_act_impl(const void* x, int ldx, const float* scale, const float* shift, const void* residual, int ldr,
+                                void* y, int ldy, long long M, int C, int act, float slope, unsigned long long* signs, int act_dtype, void* stream) {
   SV_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && ldx >= C && ldy >= C, "scale_shift_act: bad arguments");
   SV_REQUIRE_ACT(act_dtype);
   hipStream_t s = (hipStream_t)stream;
@@ -999,6 +1028,7 @@ extern "C" int sv_scale_shift_act(const void* x, int ldx, const float* scale, co
                    (((uintptr_t)scale | (uintptr_t)shift) & 15) == 0;
   const bool narrow = !vec && C <= BN_NARROW_MAXC && (ldx % 4 == 0) && (ldy % 4 == 0) && ldx >= ((C + 3) & ~3) && ldy >= ((C + 3) & ~3) &&
                       (!residual || (ldr % 4 == 0 && ldr >= ((C + 3) & ~3))) && aligned4(act_dtype, x, y, residual);
+  SV_REQUIRE(!signs || (vec && bn_signs_ok(C) && ((uintptr_t)signs & 15) == 0), "scale_shift_act_signs: needs C %% 256 == 0 and 4-aligned rows (C=%d)", C);
   if (narrow) {
     long long blocks = (M + 63) / 64; if (blocks > 8192) blocks = 8192;
     SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(scale_shift_act_narrow_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const AT*>(x), ldx, scale, shift,
@@ -1010,7 +1040,7 @@ extern "C" int sv_scale_shift_act(const void* x, int ldx, const float* scale, co
     const long long maxs = (M + 4 * RL - 1) / (4 * RL); if (splits > maxs) splits = maxs;
     const long long rpb = (M + splits - 1) / splits;
     SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(scale_shift_act_cg_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, static_cast<const AT*>(x), ldx, scale, shift,
-                                                  static_cast<const AT*>(residual), ldr, static_cast<AT*>(y), ldy, M, C, act, slope, rpb, G););
+                                                  static_cast<const AT*>(residual), ldr, static_cast<AT*>(y), ldy, M, C, act, slope, rpb, G, signs););
   } else {
     long long blocks = (M * C + 255) / 256; if (blocks > 8192) blocks = 8192;
     SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(scale_shift_act_scalar_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const AT*>(x), ldx, scale, shift,
@@ -1019,19 +1049,33 @@ extern "C" int sv_scale_shift_act(const void* x, int ldx, const float* scale, co
   return check_launch("sv_scale_shift_act");
 }
 
+extern "C" int sv_scale_shift_act(const void* x, int ldx, const float* scale, const float* shift, const void* residual, int ldr,
+                                  void* y, int ldy, long long M, int C, int act, float slope, int act_dtype, void* stream) {
+  return scale_shift_act_impl(x, ldx, scale, shift, residual, ldr, y, ldy, M, C, act, slope, nullptr, act_dtype, stream);
+}
+extern "C" int sv_bn_signs_supported(int C) { return bn_signs_ok(C) ? 1 : 0; }
+extern "C" int sv_scale_shift_act_signs(const void* x, int ldx, const float* scale, const float* shift, const void* residual, int ldr,
+                                        void* y, int ldy, long long M, int C, int act, float slope, void* signs, int act_dtype, void* stream) {
+  SV_REQUIRE(signs, "scale_shift_act_signs: null sign buffer");
+  return scale_shift_act_impl(x, ldx, scale, shift, residual, ldr, y, ldy, M, C, act, slope, static_cast<unsigned long long*>(signs), act_dtype, stream);
+}
+
 extern "C" size_t sv_bn_bwd_workspace_doubles(int C) { return (size_t)(BN_BWD_SLOTS + 1) * 2 * C + 2; }
 
-extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const void* x, int ldx, const float* gamma,
-                         const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
-                         void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws,
-                         const float* fwd_scale, const float* fwd_shift, int act_dtype, void* stream) {
+static int bn_bwd_impl(const void* dz, int lddz, const void* z, int ldz, const unsigned long long* signs, const void* x, int ldx, const float* gamma,
+                       const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
+                       void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws,
+                       const float* fwd_scale, const float* fwd_shift, int act_dtype, void* stream) {
   SV_REQUIRE(dz && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && sums_ws && M > 0 && C > 0, "bn_bwd: null/empty argument");
-  SV_REQUIRE(act == SV_ACT_NONE || z || (fwd_scale && fwd_shift), "bn_bwd: the activation mask needs the forward output z or the forward scale/shift");
+  SV_REQUIRE(act == SV_ACT_NONE || z || signs || (fwd_scale && fwd_shift), "bn_bwd: the activation mask needs the forward output z, its sign words or the forward scale/shift");
   const float* fsc = fwd_scale; const float* fsh = fwd_shift;
   SV_REQUIRE_ACT(act_dtype);
   hipStream_t s = (hipStream_t)stream;   // sums_ws: sv_bn_bwd_workspace_doubles(C) doubles, ZERO on entry (e.g. a slice of one pre-zeroed arena)
   const bool vec = (C % 4 == 0) && (lddz % 4 == 0) && (ldx % 4 == 0) && (lddx % 4 == 0) && (!z || ldz % 4 == 0) && (!dres || lddres % 4 == 0) &&
                    aligned4(act_dtype, dz, z, x, dx, dres) && (((uintptr_t)save_mean | (uintptr_t)save_rstd) & 15) == 0;
+  // sign words: the reduce pass takes the mask from them and hands the masked gradient on through dres (premask) - both vector-path features
+  SV_REQUIRE(!signs || (vec && bn_signs_ok(C) && dres && act != SV_ACT_NONE && ((uintptr_t)signs & 15) == 0),
+             "bn_bwd_signs: needs C %% 256 == 0, 4-aligned rows, an activation and the residual-branch output dres (C=%d)", C);
   SV_DISPATCH_ACT(act_dtype,
     const AT* dz_ = static_cast<const AT*>(dz); const AT* z_ = static_cast<const AT*>(z); const AT* x_ = static_cast<const AT*>(x);
     AT* dx_ = static_cast<AT*>(dx); AT* dres_ = static_cast<AT*>(dres);
@@ -1057,9 +1101,9 @@ extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const
       // mask-free, instead of (dz, z): 7 instead of 8 passes over the tensor.  The sums are of the fp32 values, the stored ones are
       // rounded to the storage type - as dres always was.
       static const int premask_on = [] { const char* v = getenv("SV_BN_PREMASK"); return v ? atoi(v) : 1; }();
-      const bool premask = premask_on && dres_ && act != SV_ACT_NONE;
+      const bool premask = (premask_on || signs) && dres_ && act != SV_ACT_NONE;
       hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<AT>, dim3(cg, cdiv(M, rpb)), dim3(256), 0, s, dz_, lddz, z_, ldz, x_, ldx, save_mean, save_rstd, M, C, act, slope,
-                         sums_ws, rpb, G, fsc, fsh, premask ? dres_ : (AT*)nullptr, lddres);
+                         sums_ws, rpb, G, fsc, fsh, premask ? dres_ : (AT*)nullptr, lddres, signs);
       hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);
       long long asplits = 4096 / cg; if (asplits < 1) asplits = 1;
       const long long amax = (M + 4 * RL - 1) / (4 * RL); if (asplits > amax) asplits = amax;
@@ -1083,4 +1127,19 @@ extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const
                          act, slope, training, dx_, lddx, dres_, lddres, dgamma, dbeta, fsc, fsh);
     });
   return check_launch("sv_bn_bwd");
+}
+
+extern "C" int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const void* x, int ldx, const float* gamma,
+                         const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
+                         void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws,
+                         const float* fwd_scale, const float* fwd_shift, int act_dtype, void* stream) {
+  return bn_bwd_impl(dz, lddz, z, ldz, nullptr, x, ldx, gamma, save_mean, save_rstd, M, C, act, slope, training, dx, lddx, dres, lddres, dgamma, dbeta,
+                     sums_ws, fwd_scale, fwd_shift, act_dtype, stream);
+}
+extern "C" int sv_bn_bwd_signs(const void* dz, int lddz, const void* signs, const void* x, int ldx, const float* gamma,
+                               const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,
+                               void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta, double* sums_ws, int act_dtype, void* stream) {
+  SV_REQUIRE(signs, "bn_bwd_signs: null sign buffer");
+  return bn_bwd_impl(dz, lddz, nullptr, 0, static_cast<const unsigned long long*>(signs), x, ldx, gamma, save_mean, save_rstd, M, C, act, slope, training,
+                     dx, lddx, dres, lddres, dgamma, dbeta, sums_ws, nullptr, nullptr, act_dtype, stream);
 }

@@ -47,7 +47,7 @@ _P, _I, _L, _F, _U, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint3
 # Entry points whose activation tensors are void* + `int act_dtype` (inserted by call() right before the stream argument)
 _ACT_TYPED = {
     "sv_conv_gather", "sv_tconv_gather", "sv_conv_wgrad", "sv_stencil3_fwd", "sv_stencil3_wgrad", "sv_colsum",
-    "sv_layernorm_fwd", "sv_layernorm_bwd", "sv_ln_image_fwd", "sv_ln_image_bwd", "sv_bn_stats", "sv_scale_shift_act", "sv_bn_bwd",
+    "sv_layernorm_fwd", "sv_layernorm_bwd", "sv_ln_image_fwd", "sv_ln_image_bwd", "sv_bn_stats", "sv_scale_shift_act", "sv_bn_bwd", "sv_scale_shift_act_signs", "sv_bn_bwd_signs",
     "sv_window_attention_fwd", "sv_window_attention_bwd", "sv_cross_view_attention_fwd", "sv_cross_view_attention_bwd",
     "sv_transpose", "sv_add_n", "sv_axpby", "sv_relu_bwd", "sv_maxpool2d_fwd", "sv_maxpool2d_bwd", "sv_avgpool2_fwd", "sv_avgpool2_bwd",
     "sv_decoder_seed_fwd", "sv_decoder_seed_bwd", "sv_maxpool3d_fwd", "sv_maxpool3d_bwd", "sv_dropout", "sv_rowscale",
@@ -83,6 +83,9 @@ _PROTOS = {
     "sv_bn_finalize": (_I, [_P, _L, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _I]),
     "sv_scale_shift_act": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _F]),
     "sv_bn_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _L, _I, _I, _F, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P]),
+    "sv_bn_signs_supported": (_I, None, [_I]),
+    "sv_scale_shift_act_signs": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _F, _P]),
+    "sv_bn_bwd_signs": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _L, _I, _I, _F, _I, _P, _I, _P, _I, _P, _P, _P]),
     "sv_window_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "sv_window_attention_bwd_workspace_floats": (C.c_size_t, None, [_I]),
     "sv_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),

@@ -585,14 +585,38 @@ class BatchNormState:
         probe = _STATE.get("bn_probe")
         if probe is not None:        # debug hook (tests): the producer's statistics next to the output it stored
             probe(self, x, ldx)
+        self.signs = None
+        if (residual is not None and act != ACT_NONE and self.training and _bn_signs_on() and self.C % 256 == 0
+                and self.C % 4 == 0 and ldx % 4 == 0 and ldy % 4 == 0 and ldr % 4 == 0):
+            # BatchNorm in front of a residual sum: the backward's activation mask as sign words (1/16 of the output's bytes) - see backward()
+            self.signs = torch.empty(self.M * (self.C // 64), dtype=torch.int64, device=x.device)
+            call("sv_scale_shift_act_signs", ptr(x), ldx, ptr(self.scale), ptr(self.shift), ptr(residual), ldr, ptr(y), ldy, self.M, self.C, act, slope,
+                 ptr(self.signs))
+            return
         call("sv_scale_shift_act", ptr(x), ldx, ptr(self.scale), ptr(self.shift), ptr(residual), ldr, ptr(y), ldy, self.M, self.C, act, slope)
 
     def backward(self, dz, lddz, z, ldz, x, ldx, dx, lddx, dgamma, dbeta, act=ACT_NONE, slope=0.0, dres=None, lddres=0):
         ws = zeros_f64((BN_BWD_SLOTS + 1) * 2 * self.C + 2, dz.device)     # sv_bn_bwd_workspace_doubles(C), zero on entry
+        if getattr(self, "signs", None) is not None and dres is not None:
+            # mask from the forward's sign words: the reduce pass reads (dz, x, words) and stores the masked gradient in dres, the apply pass
+            # reads (dres, x): 6 passes over the tensor instead of the 8 of (dz, z, x) + (dz, z, x, dx, dres)
+            call("sv_bn_bwd_signs", ptr(dz), lddz, ptr(self.signs), ptr(x), ldx, ptr(self.bn.weight), ptr(self.mean), ptr(self.rstd), self.M, self.C,
+                 act, slope, 1 if self.training else 0, ptr(dx), lddx, ptr(dres), lddres, ptr(dgamma), ptr(dbeta), ptr(ws))
+            return
         # z = None: the forward added no residual, so the activation mask is recomputed from x (one tensor read less per pass)
         call("sv_bn_bwd", ptr(dz), lddz, ptr(z), ldz, ptr(x), ldx, ptr(self.bn.weight), ptr(self.mean), ptr(self.rstd), self.M, self.C,
              act, slope, 1 if self.training else 0, ptr(dx), lddx, ptr(dres), lddres, ptr(dgamma), ptr(dbeta), ptr(ws),
              ptr(self.scale), ptr(self.shift))
+
+
+def _bn_signs_on() -> bool:
+    import os
+    return _STATE.get("bn_signs", os.environ.get("SV_BN_SIGNS", "1") != "0")
+
+
+def set_bn_signs(on: bool) -> None:
+    """A/B switch: False keeps the stored output as the activation mask of the BatchNorms in front of a residual sum."""
+    _STATE["bn_signs"] = bool(on)
 
 
 def set_bn_probe(fn) -> None:

@@ -430,12 +430,14 @@ def test_ln_image(dev, I, Cc, H):
     assert rel(dw, w.grad.permute(1, 2, 0).reshape(L)) < TOL and rel(db, b.grad.permute(1, 2, 0).reshape(L)) < TOL
 
 
-@pytest.mark.parametrize("act", [ACT_RELU, ACT_LRELU, ACT_NONE])
-def test_batchnorm_train_fwd_bwd(dev, act):
+@pytest.mark.parametrize("act,M,Cc", [(ACT_RELU, 500, 40), (ACT_LRELU, 500, 40), (ACT_NONE, 500, 40),
+                                      # C % 256 == 0 with a residual: the activation mask travels as sign words (sv_scale_shift_act_signs /
+                                      # sv_bn_bwd_signs), the masked gradient through dres; odd row counts exercise the two-row loop's tail
+                                      (ACT_RELU, 1031, 256), (ACT_LRELU, 517, 512), (ACT_RELU, 4099, 1024)])
+def test_batchnorm_train_fwd_bwd(dev, act, M, Cc):
     g = torch.Generator().manual_seed(6)
-    M, Cc = 500, 40
     x = (torch.randn(M, Cc, generator=g) * 2 + 0.5).requires_grad_(True)
-    res = torch.randn(M, Cc, generator=g)
+    res = torch.randn(M, Cc, generator=g).requires_grad_(True)
     bn = torch.nn.BatchNorm1d(Cc)
     with torch.no_grad():
         bn.weight.copy_(1 + 0.1 * torch.randn(Cc, generator=g)); bn.bias.copy_(0.1 * torch.randn(Cc, generator=g))
@@ -451,13 +453,15 @@ def test_batchnorm_train_fwd_bwd(dev, act):
     call("sv_bn_stats", ptr(xd), M, Cc, Cc, ptr(st.sums))
     st.finalize()
     zd = ops.empty(M, Cc, device=dev)
-    st.apply(xd, Cc, zd, Cc, act, 0.2, res.to(dev), Cc)
+    st.apply(xd, Cc, zd, Cc, act, 0.2, res.detach().to(dev), Cc)
+    assert (st.signs is not None) == (Cc % 256 == 0 and act != ACT_NONE)
     assert rel(zd, z) < TOL
     assert rel(bn_d.running_mean, bn.running_mean) < 1e-4 and rel(bn_d.running_var, bn.running_var) < 1e-4
     dx, dres = ops.empty(M, Cc, device=dev), ops.empty(M, Cc, device=dev)
     dg, db = ops.zeros(Cc, device=dev), ops.zeros(Cc, device=dev)
     st.backward(dz.to(dev), Cc, zd, Cc, xd, Cc, dx, Cc, dg, db, act, 0.2, dres, Cc)
     assert rel(dx, x.grad) < 5e-4 and rel(dg, bn.weight.grad) < 5e-4 and rel(db, bn.bias.grad) < 5e-4
+    assert rel(dres, res.grad) < 1e-6          # the residual branch's gradient = dz * act'(z)
 
 
 # ------------------------------------------------------------------------------------------------ attention
