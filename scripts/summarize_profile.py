@@ -25,6 +25,8 @@ def family(name: str) -> str:
         return "contraction engine (igemm_kernel + gemm_dense_kernel + gemm_wide_kernel + wgrad_kernel + wgrad_wide_kernel)"
     if "swin_attn_block_fwd" in n:
         return "fused Swin attention branch forward (swin_attn_block_fwd_kernel)"
+    if "swin_attn_block_bwd" in n:
+        return "fused Swin attention branch backward (swin_attn_block_bwd_kernel)"
     if "win_attn_fwd" in n:
         return "window attention forward (win_attn_fwd_*)"
     if "win_attn_bwd" in n:
@@ -56,7 +58,7 @@ def main():
     out = {"tag": a.tag, "kernel_source_hash": kernel_source_hash()}    # the build the counters describe (bench.py checks it)
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     if a.stats:
-        f = glob.glob(os.path.join(a.stats, "*", "*_kernel_stats.csv"))[0]
+        f = max(glob.glob(os.path.join(a.stats, "*", "*_kernel_stats.csv")), key=os.path.getmtime)   # gpurun_out/ is merged across calls: the newest run
         shutil.copy(f, os.path.join(ROOT, "profiles", f"{a.tag}_kernel_stats.csv"))
         rows = list(csv.DictReader(open(f)))
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -71,7 +73,7 @@ def main():
             for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])[:20]}}
     if a.fetch and a.write:
         def load(d):
-            f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+            f = max(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
             agg = collections.defaultdict(lambda: [0, 0.0])
             for r in csv.DictReader(open(f)):
                 k = family(r["Kernel_Name"])
@@ -92,7 +94,7 @@ def main():
         # MFMA utilisation per kernel family: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the SIMDs: 32 per v_mfma_f32_32x32x16_bf16,
         # 16 per 16x16x32 - MI355X_MICROARCH.md cycle constants) against the SIMD-cycles the dispatch had: GRBM_GUI_ACTIVE (summed over the
         # 8 XCDs) / 8 x 1024 SIMDs.  Calibration: the fused MLP forward issues a known number of MFMAs (see profiles/README.md).
-        f = glob.glob(os.path.join(a.mfma, "*", "*_counter_collection.csv"))[0]
+        f = max(glob.glob(os.path.join(a.mfma, "*", "*_counter_collection.csv")), key=os.path.getmtime)
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         cnt = collections.defaultdict(int)
         for r in csv.DictReader(open(f)):
