@@ -18,7 +18,7 @@ from swinvox_amd.ops import ConvSpec  # noqa: E402
 LINEAR = [(12544, 384, 1536), (12544, 1536, 384), (12544, 384, 1152), (12544, 384, 384), (200704, 96, 384), (200704, 384, 96),
           (200704, 96, 288), (200704, 96, 96), (50176, 192, 768), (50176, 768, 192), (50176, 192, 576), (3136, 768, 3072), (3136, 3072, 768)]
 CONV = [  # n, H, cin, cout, k, s, p
-    (64, 56, 64, 256, 1, 1, 0), (64, 56, 256, 64, 1, 1, 0), (64, 56, 64, 64, 3, 1, 1), (64, 28, 128, 512, 1, 1, 0), (64, 28, 512, 128, 1, 1, 0),
+    (64, 56, 64, 256, 1, 1, 0), (64, 56, 256, 64, 1, 1, 0), (64, 56, 64, 64, 3, 1, 1), (512, 56, 64, 64, 3, 1, 1), (512, 28, 128, 128, 3, 1, 1), (512, 14, 256, 256, 3, 1, 1), (64, 28, 128, 512, 1, 1, 0), (64, 28, 512, 128, 1, 1, 0),
     (64, 28, 128, 128, 3, 1, 1), (64, 14, 256, 1024, 1, 1, 0), (64, 14, 1024, 256, 1, 1, 0), (64, 14, 256, 256, 3, 1, 1), (64, 56, 256, 256, 3, 2, 1)]
 
 

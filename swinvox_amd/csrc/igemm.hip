@@ -648,10 +648,18 @@ __global__ __launch_bounds__(TL::NTHR, TL::NTHR == 512 ? 4 : 2) void igemm_kerne
         int id, ih, iw;
         if constexpr (TCONV) { id = a_d[i] - td; ih = a_h[i] - th; iw = a_w[i] - tw; }
         else { id = a_d[i] + td; ih = a_h[i] + th; iw = a_w[i] + tw; }
+#ifdef SV_IG_PROBE_CHEAPADDR     // probe build (wrong results): what the gather's coordinate / bounds / address arithmetic costs the K loop
+        const bool ok = kok && a_ok[i];
+        if (ok) {
+          const size_t off = (size_t)(row0 + rb + RPP * i) * (size_t)g.ldi + kc;
+          (void)id; (void)ih; (void)iw;
+          ra[i] = VecN<AT, VEC>::load(X + off);
+#else
         const bool ok = kok && a_ok[i] && (unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi;
         if (ok) {
           const size_t off = ((((size_t)a_n[i] * g.Di + id) * g.Hi + ih) * g.Wi + iw) * (size_t)g.ldi + kc;
           ra[i] = VecN<AT, VEC>::load(X + off);
+#endif
         } else {
           ra[i] = VecN<AT, VEC>::zero();
         }
