@@ -34,7 +34,7 @@ def synth_gt(B, seed):
     return (torch.rand(B, 32, 32, 32, generator=g) < 0.10).float()
 
 
-def grad_report(items, factor=4.0, floor_l1=5e-3, floor_max=5e-2):
+def grad_report(items, factor=4.0, floor_l1=3e-3, floor_max=2.5e-2):
     """items: (name, hip_grad, oracle_fp32_grad, oracle_fp64_grad); the fp64 run of the oracle is the truth.
 
     Two fp32 forwards (HIP vs CPU) differ by rounding, so a max-pool arg-max or a (Leaky)ReLU mask occasionally flips
@@ -42,9 +42,12 @@ def grad_report(items, factor=4.0, floor_l1=5e-3, floor_max=5e-2):
     (measured: scripts/grad_mask_flip_study.py - the contraction kernels themselves are exact to 3e-7 on the same
     tensors).  Train-mode BatchNorm over a handful of images additionally makes some ResNet gradients ill-conditioned:
     the CPU fp32 oracle itself is up to 17% off the fp64 truth there.  Hence: the L1-relative error must be within
-    `factor` x the CPU-fp32 oracle's own L1 error + floor_l1, and the max-norm error within factor x e32 + floor_max;
+    `factor` x the CPU-fp32 oracle's own L1 error + floor_l1, and the max-norm error within factor x e32 + floor_max (round 3: floors
+    3e-3 / 2.5e-2, down from 5e-3 / 5e-2 - the largest excess measured over the whole train step is 1.9e-3 / 1.3e-2, one re-routed
+    max-pool / ReLU element in `encoder.layer3.0.weight`; the tail modules alone stay below 4e-4 / 8e-4);
     analytically-zero gradients (conv biases in front of a train-mode BatchNorm) are compared absolutely."""
     bad = []
+    worst_l1, worst_mx = (0.0, ""), (0.0, "")          # largest excess over factor x the CPU-fp32 error: what the floors have to cover
     for name, gh, g32, g64 in items:
         gh, g32, g64 = gh.detach().cpu().double(), g32.detach().double(), g64.detach()
         scale = float(g64.abs().max())
@@ -55,8 +58,11 @@ def grad_report(items, factor=4.0, floor_l1=5e-3, floor_max=5e-2):
         l1 = float(g64.abs().sum())
         e_hip_l1, e_32_l1 = float((gh - g64).abs().sum()) / l1, float((g32 - g64).abs().sum()) / l1
         e_hip_mx, e_32_mx = float((gh - g64).abs().max()) / scale, float((g32 - g64).abs().max()) / scale
+        worst_l1 = max(worst_l1, (e_hip_l1 - factor * e_32_l1, name))
+        worst_mx = max(worst_mx, (e_hip_mx - factor * e_32_mx, name))
         if e_hip_l1 > factor * e_32_l1 + floor_l1 or e_hip_mx > factor * e_32_mx + floor_max:
             bad.append((name, e_hip_l1, e_32_l1, e_hip_mx, e_32_mx))
+    print(f"grad_report: largest excess over {factor} x CPU-fp32 error: L1 {worst_l1[0]:.2e} ({worst_l1[1]}), max-norm {worst_mx[0]:.2e} ({worst_mx[1]})")
     return bad
 
 
