@@ -539,6 +539,39 @@ def test_cross_view_attention_core(dev, V, P):
     assert rel(dq, qkv.grad) < TOL
 
 
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_batched_weight_packs_equal_the_single_packs(dev, storage):
+    """ops.PackCache (every pack of a module from ONE sv_pack_weights launch - the data-gradient packs of Linear / 1x1 layers go through its
+    LDS-tiled transpose) against sv_pack_weight, pack by pack, bit for bit: linears with and without 64-multiples, convolutions, transposed
+    convolutions, zero-padded channel counts."""
+    g = torch.Generator().manual_seed(21)
+    specs = [ConvSpec.linear(2048, 8192), ConvSpec.linear(384, 1536), ConvSpec.linear(96, 288), ConvSpec.linear(1024, 256), ConvSpec.linear(40, 72),
+             ConvSpec.conv2d(64, 64, 3, 1, 1), ConvSpec.conv2d(256, 128, 1, 2, 0), ConvSpec.conv3d(9, 9, 3, 1, 1, cin_mem=12, cout_mem=12),
+             ConvSpec.conv3d(32, 8, 4, 2, 1, transposed=True), ConvSpec.linear(64, 256)]
+    ops.set_math("bf16" if storage == "bf16" else "f32")
+    if storage == "bf16":
+        ops.set_storage("bf16")
+    try:
+        params = []
+        for sp in specs:
+            shape = (sp.cin, sp.cout) + sp.k if sp.transposed else (sp.cout, sp.cin) + sp.k
+            params.append(torch.nn.Parameter(torch.randn(*shape, generator=g).to(dev)))
+        cache = ops.PackCache()
+        ops.set_pack_cache(cache)
+        try:
+            first = [(sp.pack_fwd(w), sp.pack_dgrad(w)) for sp, w in zip(specs, params)]       # registers the requests (single packs)
+            cache.refresh()                                                                     # one batched launch
+            second = [(sp.pack_fwd(w), sp.pack_dgrad(w)) for sp, w in zip(specs, params)]      # views of the batched buffer
+        finally:
+            ops.set_pack_cache(None)
+        torch.cuda.synchronize()
+        for sp, (f1, d1), (f2, d2) in zip(specs, first, second):
+            assert torch.equal(f1.reshape(-1).float(), f2.reshape(-1).float()), ("fwd", sp)
+            assert torch.equal(d1.reshape(-1).float(), d2.reshape(-1).float()), ("dgrad", sp)
+    finally:
+        ops.set_math("f32")
+
+
 # ------------------------------------------------------------------------------------------------ glue kernels
 def test_transpose_and_pools(dev):
     g = torch.Generator().manual_seed(8)
