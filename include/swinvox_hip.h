@@ -304,6 +304,11 @@ int sv_swin_attn_block_bwd(const void* dx1, const void* qkv, const void* x, cons
  *  sv_stem_unpack_grad: dw [64,3,7,7] += dw16 [64][16][4][4];
  *  sv_merger_pack: w [cout][cin][27] fp32 -> bf16 forward pack [16][27][16 | 48] or data-gradient pack [16 | 48][27][16] (taps flipped);
  *                  concat = 1: the 36 input channels sit at columns 12 g + j of the four 12-wide planes.                              */
+/* Refiner head Conv3d(1, Co, k = 4, p = 2) on a D^3 grid (reference models/refiner.py:21-26) as a (4, 1, 1)-tap convolution over 16 channels (the stem's
+ * trick): xc [N, D, D+1, D+1, 16] with xc[.., Y, X, 4 cy + cx] = x[.., Y + cy - 2, X + cx - 2] (zero outside); sv_head_unpack_dx folds the
+ * 16-channel data gradient of that convolution back into dx [N, D, D, D]. */
+int sv_head_pack_x(const void* x, void* xc, int N, int D, int act_dtype, void* stream);
+int sv_head_unpack_dx(const void* dxc, void* dx, int N, int D, int act_dtype, void* stream);
 int sv_stem_space_to_depth(const void* images, void* x16, int I, int act_dtype, void* stream);
 int sv_stem_pack(const float* w, void* wp, int out_dtype, void* stream);
 int sv_stem_unpack_grad(const float* dw16, float* dw, void* stream);

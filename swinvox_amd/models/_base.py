@@ -172,7 +172,7 @@ class ConvBnAct:
         sp = self.spec
         og = sp.out_grid(in_grid)
         M = n * og[0] * og[1] * og[2]
-        wf = sp.pack_fwd(self.conv.weight)
+        wf = self._pack("f")
         y = empty(M, sp.cout, like=x)
         st = BatchNormState(self.bn, M, training)
         sp.forward(x, n, in_grid, wf, y, ldi=ldi, bias=self.conv.bias, stats=st.sums)
@@ -189,7 +189,7 @@ class ConvBnAct:
         dy = (zeros if sp.cout_mem != sp.cout else empty)(M, sp.cout_mem, like=dz)
         st.backward(dz, lddz, z, ldz, y, sp.cout, dy, sp.cout_mem, grads[self.bn.weight], grads[self.bn.bias], self.act, self.slope,
                     dres, lddres)
-        sp.wgrad(dy, x, n, in_grid, grads[self.conv.weight], lddy=sp.cout_mem, ldx=ldi,
+        sp.wgrad(dy, x, n, in_grid, self._dw(grads), lddy=sp.cout_mem, ldx=ldi,
                  db=grads[self.conv.bias] if self.conv.bias is not None else None)
         if not need_dx:
             return None
@@ -197,8 +197,15 @@ class ConvBnAct:
         if dx is None:
             dx = (zeros if sp.cin_mem != sp.cin else empty)(Min, sp.cin_mem, like=dz)
             lddx = sp.cin_mem
-        sp.dgrad(dy, n, in_grid, sp.pack_dgrad(self.conv.weight), dx, lddy=sp.cout_mem, lddx=lddx, **(dx_epi or {}))
+        sp.dgrad(dy, n, in_grid, self._pack("d"), dx, lddy=sp.cout_mem, lddx=lddx, **(dx_epi or {}))
         return dx
+
+    # the two places a layer that runs on a re-indexed weight (Refiner head) overrides
+    def _pack(self, kind):
+        return self.spec.pack_fwd(self.conv.weight) if kind == "f" else self.spec.pack_dgrad(self.conv.weight)
+
+    def _dw(self, grads):
+        return grads[self.conv.weight]
 
 
 def conv_spec_of(m: nn.Module, **kw) -> ConvSpec:
