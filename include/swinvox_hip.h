@@ -84,6 +84,13 @@ typedef struct sv_epilogue {
  * gather form:  out[o, co] = sum_{tap,ci} in[o*s - p + tap, ci] * w[co, tap, ci]      (conv forward; tconv data-grad; Linear) */
 int sv_conv_gather(const void* in, const void* w_packed, void* out, const sv_geom* g, const sv_epilogue* e,
                    int math, int act_dtype, void* stream);
+/* Halo-tile kernels behind sv_conv_gather / sv_tconv_gather (bf16 storage + bf16 MFMA, plain store with optional statistics): 3 x 3 / stride 1 /
+ * padding 1 with Ci = Co = 64 (forward and data gradient) and the 4 x 4 / pads (2, 1) ResNet stem on the space-to-depth image (Ci = 16, Co = 64)
+ * keep the weights in LDS and read each input patch once instead of once per tap.  mode 0: off, 1 (default; SV_CONV_HALO in the environment):
+ * calls of >= 256 tiles of 8 x 32 positions, 2: every call of those shapes.  Results differ from the gather engine's only in fp32 summation order. */
+int sv_set_conv_halo(int mode);
+int sv_conv_halo_mode(void);
+long long sv_conv_halo_launches(void); /* calls taken by the halo-tile kernels so far in this process (tests: the path they mean to exercise) */
 /* 1 when sv_conv_gather would run this call on the wide dense kernel (256 x 128 tile, LDS-DMA operand ring: Linear / 1x1 layers with
  * bf16 storage, K % 32 == 0, K >= 128, Co >= 128, 8-aligned rows and >= 256 tiles), else 0.  SV_GEMM_WIDE=0 in the environment disables it. */
 int sv_conv_gather_is_wide(const void* in, const void* w, void* out, const sv_geom* g, const sv_epilogue* e, int math, int act_dtype);

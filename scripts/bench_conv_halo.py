@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Halo-tile kernels (csrc/conv_halo.hip) against the gather engine on the calls they take: 3 x 3 / 64 -> 64 at 56 x 56 (forward with BatchNorm
+statistics, data gradient) and the 4 x 4 stem at 112 x 112, 512 images, bf16."""
+import math, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import swinvox_amd as S
+from swinvox_amd import hip, ops
+from swinvox_amd.ops import ConvSpec
+dev = torch.device("cuda", 0); hip.load(); S.set_math("bf16"); S.set_storage("bf16")
+def timeit(fn, iters=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+n = int(os.environ.get("SV_I", "512"))
+for name, sp, H, ci, k in (("3x3 64->64 @56", ConvSpec.conv2d(64, 64, 3, 1, 1), 56, 64, 3),
+                           ("stem 4x4 16->64 @112", ConvSpec.conv2d(16, 64, 4, 1, 2, og_fixed=(1, 112, 112)), 112, 16, 4)):
+    M = n * H * H
+    x = torch.randn(M, ci, device=dev).bfloat16()
+    dy = torch.randn(M, 64, device=dev).bfloat16()
+    w = torch.randn(64, ci, k, k, device=dev) / math.sqrt(ci * k * k)
+    wf, wd = ops.pack_one(sp, w, "f"), ops.pack_one(sp, w, "d")
+    out, dx = ops.empty(M, 64, device=dev), ops.empty(M, ci, device=dev)
+    stats = torch.zeros(ops.BN_SLOTS, 128, dtype=torch.float64, device=dev)
+    flops = 2.0 * M * k * k * ci * 64
+    mb = (M * ci + M * 64) * 2 / 1e6
+    for mode in (0, 2):
+        ops.set_conv_halo(mode)
+        tf = timeit(lambda: sp.forward(x, n, (1, H, H), wf, out, stats=stats))
+        line = f"{name}  mode {mode}: forward+stats {tf:7.1f} us ({flops / tf / 1e6:6.1f} TF/s, {mb / tf * 1e3:5.0f} GB/s)"
+        if ci == 64:
+            td = timeit(lambda: sp.dgrad(dy, n, (1, H, H), wd, dx))
+            line += f"   data gradient {td:7.1f} us ({flops / td / 1e6:6.1f} TF/s)"
+        print(line)

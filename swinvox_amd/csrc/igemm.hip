@@ -16,6 +16,7 @@
 // K-step 32 (fp32) or 64 (bf16); global->register prefetch of step k+1 under the MFMAs of step k
 // (register-staged: the gather needs per-element predication and an fp32->bf16 conversion).
 #include "common.h"
+#include "conv_halo.h"
 #include <stdlib.h>
 #include <atomic>
 #include <mutex>
@@ -1546,6 +1547,26 @@ static int* gemm_wide_counters() {     // next launch slot of the current device
   return c ? c->buf + 16 * (c->next.fetch_add(1) % GW_SLOTS) : nullptr;
 }
 
+int* tile_draw_counters() { return gemm_wide_counters(); }
+
+// Halo-tile kernels (conv_halo.hip) take the two shapes they are built for - 3 x 3 / stride 1 / 64 -> 64 (forward and data gradient) and
+// the 4 x 4 stem on the space-to-depth image - when the call is a plain store (+ BatchNorm statistics); 0 = not taken
+static int try_halo(const void* in, const void* w, void* out, const sv_geom* g, const sv_epilogue* e, int math, int act_dtype, bool dgrad,
+                    hipStream_t s) {
+  if (math != SV_MATH_BF16 || act_dtype != SV_BF16 || !conv_halo_enabled()) return 0;
+  if (g->Co != 64 || g->kd != 1 || g->Di != 1 || g->Do != 1 || g->sd != 1 || g->sh != 1 || g->sw != 1 || g->pd != 0) return 0;
+  if (g->Hi != g->Ho || g->Wi != g->Wo || g->ldi != g->Ci) return 0;
+  if (e->bias || e->residual || e->row_scale || e->pre_act || e->act != SV_ACT_NONE || e->act_grad_src || e->ldc != 64 || e->col_off != 0) return 0;
+  if (((uintptr_t)in | (uintptr_t)w | (uintptr_t)out) & 15) return 0;
+  int kind;
+  if (g->kh == 3 && g->kw == 3 && g->ph == 1 && g->pw == 1 && g->Ci == 64) kind = 0;
+  else if (!dgrad && g->kh == 4 && g->kw == 4 && g->ph == 2 && g->pw == 2 && g->Ci == 16) kind = 1;
+  else return 0;
+  if (dgrad && e->stats) return 0;
+  HaloConvArgs a{in, w, out, e->stats, g->N, g->Hi, g->Wi, dgrad ? 1 : 0};
+  return conv_halo_launch(a, kind, s);
+}
+
 // the wide kernel takes the dense layers whose K loop is worth a DMA ring and whose tile count fills the chip;
 // SV_GEMM_WIDE=0 in the environment keeps every layer on the 128-wide kernels (A/B measurements)
 static bool gemm_wide_ok(const IGemmArgs& a, long long M) {
@@ -1808,6 +1829,7 @@ extern "C" int sv_conv_gather(const void* in, const void* w, void* out, const sv
   if (int rc = check_common(g, e, in, w, out, act_dtype)) return rc;
   SV_REQUIRE_ACT(act_dtype);
   SV_REQUIRE(act_dtype == SV_F32 || math == SV_MATH_BF16, "igemm: bf16 activations require SV_MATH_BF16");
+  if (try_halo(in, w, out, g, e, math, act_dtype, false, (hipStream_t)stream)) return check_launch("sv_conv_gather (halo tiles)");
   IGemmArgs a{};
   a.x = in; a.w = w; a.y = out; a.g = to_geom(g); a.e = to_epi(e);
   a.Ktot = g->kd * g->kh * g->kw * g->Ci;
@@ -1835,6 +1857,7 @@ extern "C" int sv_tconv_gather(const void* in, const void* w, void* out, const s
   SV_REQUIRE_ACT(act_dtype);
   SV_REQUIRE(act_dtype == SV_F32 || math == SV_MATH_BF16, "igemm: bf16 activations require SV_MATH_BF16");
   SV_REQUIRE(g->sd <= 2 && g->sh <= 2 && g->sw <= 2, "tconv_gather: stride > 2 unsupported (%d,%d,%d)", g->sd, g->sh, g->sw);
+  if (try_halo(in, w, out, g, e, math, act_dtype, true, (hipStream_t)stream)) return check_launch("sv_tconv_gather (halo tiles)");
   IGemmArgs a{};
   a.x = in; a.w = w; a.y = out; a.g = to_geom(g); a.e = to_epi(e);
   a.Ktot = g->kd * g->kh * g->kw * g->Ci;

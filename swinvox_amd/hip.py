@@ -90,6 +90,9 @@ _PROTOS = {
     "sv_window_attention_bwd_workspace_floats": (C.c_size_t, None, [_I]),
     "sv_window_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "sv_stem_space_to_depth": (_I, [_P, _P, _I]),
+    "sv_set_conv_halo": (_I, None, [_I]),
+    "sv_conv_halo_mode": (_I, None),
+    "sv_conv_halo_launches": (_L, None),
     "sv_head_pack_x": (_I, [_P, _P, _I, _I]),
     "sv_head_unpack_dx": (_I, [_P, _P, _I, _I]),
     "sv_stem_pack": (_I, [_P, _P, _I]),

@@ -619,6 +619,14 @@ def set_bn_signs(on: bool) -> None:
     _STATE["bn_signs"] = bool(on)
 
 
+def set_conv_halo(mode: int) -> None:
+    """Halo-tile kernels behind the contraction engine (csrc/conv_halo.hip: 3 x 3 / 64 -> 64 and the ResNet stem): 0 off, 1 calls of
+    >= 256 tiles (default), 2 every call of those shapes.  Process-wide; the library reads SV_CONV_HALO for its initial mode."""
+    rc = hip.load().sv_set_conv_halo(int(mode))
+    if rc != 0:
+        raise RuntimeError(f"sv_set_conv_halo failed (rc={rc}): {hip.load().sv_last_error().decode()}")
+
+
 def set_bn_probe(fn) -> None:
     """Debug hook of the tests: fn(state, stored_output, ld) is called for every BatchNorm layer right before its normalisation pass,
     when `state.sums` (the [BN_SLOTS][2C] double partial sums the producing kernel's epilogue accumulated) and the producer's stored
