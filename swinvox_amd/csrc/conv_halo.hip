@@ -11,7 +11,8 @@
 //   * all taps run from that patch: per tap and 16 channels a wave reads 2 weight fragments and 2 patch fragments (ds_read_b128, XOR-swizzled:
 //     conflict-free) for 4 v_mfma_f32_32x32x16_bf16 - weights are the A operand, so a lane ends up with CHANNELS of one position,
 //   * the 64 x 64 result of a wave turns through a private 8 KB LDS patch into 16-byte lanes: one store instruction = 8 whole 128-byte rows,
-//   * BatchNorm statistics stay in registers across all tiles of the workgroup: one reduction and 128 double atomics per wave per LAUNCH.
+//   * BatchNorm statistics: per tile a lane sums two channels of one tile row from the staging image (fixed order), then adds into four
+//     double registers that live across all tiles of the workgroup: 256 double atomics per wave per LAUNCH.
 // Tiles are drawn at run time from per-XCD counters (a static share stalls the launch when another stream's kernel holds a CU: DESIGN 4b).
 // What bounds it then: the output stream (kind 0: 205 MB in + 205 MB out per launch at 512 images).
 #include "common.h"
@@ -21,9 +22,20 @@
 
 namespace sv {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef SV_HC_PROFILE   // cycles of workgroup 0 / thread 0 per phase: [0] preamble, [1] patch issue, [2] contraction, [3] patch store, [4] epilogue, [5] tiles
+__device__ long long hc_prof[8];
+__device__ long long hc_wg[256][4];   // per workgroup: wall-clock (100 MHz) at start / loop start / end, tiles
+#define HC_T(v) const long long v = clock64()
+#define HC_ADD(i, a, b) if (blockIdx.x == 0 && tid == 0) hc_prof[i] += (b) - (a)
+#else
+#define HC_T(v)
+#define HC_ADD(i, a, b)
+#endif
 
-// 16-byte slot s of row r of an LDS image holds source chunk s ^ hc_swz(r): the four 16-lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// weight image: 16-byte slot s of row r holds source chunk s ^ hc_swz(r): the four 16-lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}
 // ...: rows r0 + those) then touch 16 different bank slots.  128-byte rows: (r / 2) mod 8 (rows r, r + 1 differ in the 128-byte half);
 // 32-byte rows: bit 3 of r (rows r, r + 8 share a slot pair, the XOR sends them to different halves of it)
 template <int CI> __device__ __forceinline__ int hc_swz(int r) { return CI == 64 ? ((r >> 1) & 7) : ((r >> 3) & 1); }
@@ -33,7 +45,12 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloConvArgs p,
   constexpr int TH = 8, TW = 32, T = KH * KW, PH = TH + KH - 1, PW = TW + KW - 1, NPOS = PH * PW;
   constexpr int CH = CI / 8, ROWB = CI * 2, KS = CI / 16;
   constexpr int NCH = NPOS * CH, NLD = (NCH + 255) / 256;
-  constexpr int W_BYTES = T * 64 * ROWB, PATCH_BYTES = (NPOS * ROWB + 127) / 128 * 128, STAGE_BYTES = 4 * 8192;
+  // patch rows are PADDED by 16 bytes instead of swizzled (pitch 144 / 48 bytes = 9 / 3 sixteen-byte slots, odd: 16 positions of a read
+  // group land on 16 different slots), so a fragment address is lane base + a compile-time offset per (tap, slice): no address arithmetic
+  // between the MFMAs.  The weight image cannot afford the padding (82,944 + 48,960 + 32,768 B > 160 KB) and keeps the XOR, whose four
+  // variants per lane are loop constants.
+  constexpr int PROWB = ROWB + 16;
+  constexpr int W_BYTES = T * 64 * ROWB, PATCH_BYTES = (NPOS * PROWB + 127) / 128 * 128, STAGE_BYTES = 4 * 8192;
   constexpr int WCH = T * 64 * CH;
   __shared__ __attribute__((aligned(1024))) char smem[W_BYTES + PATCH_BYTES + STAGE_BYTES + 16];
   const __bf16* __restrict__ X = static_cast<const __bf16*>(p.x);
@@ -41,6 +58,10 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloConvArgs p,
   __bf16* __restrict__ Y = static_cast<__bf16*>(p.y);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kg = lane >> 5;
   const int H = p.H, Wd = p.W;
+  HC_T(t_begin);
+#ifdef SV_HC_PROFILE
+  const long long wall_begin = wall_clock64();
+#endif
   char* Wl = smem;
   char* Pl = smem + W_BYTES;
   char* Sl = smem + W_BYTES + PATCH_BYTES + wave * 8192;
@@ -54,11 +75,23 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloConvArgs p,
     mbox[0] = v0 < csize ? cbase + v0 : -1;
     mbox[1] = v1 < csize ? cbase + v1 : -1;
   }
-  // ---- weights -> LDS, once: pack row r = output channel, [tap][CI]; LDS image [tap slot][r][CI] with swizzled 16-byte slots
-  for (int id = tid; id < WCH; id += 256) {
-    const int c = id % CH, rt = id / CH, t = rt % T, r = rt / T;
-    const int ts = p.flip ? T - 1 - t : t;
-    *reinterpret_cast<bf16x8*>(Wl + (ts * 64 + r) * ROWB + ((c ^ hc_swz<CI>(r)) << 4)) = *reinterpret_cast<const bf16x8*>(Wt + (size_t)id * 8);
+  // ---- weights -> LDS, once: pack row r = output channel, [tap][CI]; LDS image [tap slot][r][CI] with swizzled 16-byte slots.  All loads
+  // of a thread are in flight together (a load - wait - store loop is 18 global round trips in a row)
+  {
+    constexpr int NWL = (WCH + 255) / 256;
+    u32x4 wr[NWL];
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) {
+      const int id = tid + 256 * j;
+      if (WCH % 256 == 0 || id < WCH) wr[j] = *reinterpret_cast<const u32x4*>(Wt + (size_t)id * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) {
+      const int id = tid + 256 * j;
+      const int c = id % CH, rt = id / CH, t = rt % T, r = rt / T;
+      const int ts = p.flip ? T - 1 - t : t;
+      if (WCH % 256 == 0 || id < WCH) *reinterpret_cast<u32x4*>(Wl + (ts * 64 + r) * ROWB + ((c ^ hc_swz<CI>(r)) << 4)) = wr[j];
+    }
   }
   __syncthreads();
   int cur = __builtin_amdgcn_readfirstlane(mbox[0]), nxt = __builtin_amdgcn_readfirstlane(mbox[1]);
@@ -76,46 +109,69 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloConvArgs p,
     const int r = t - n * tpi, th = r / tiles_w;
     h0 = th * TH; w0 = (r - th * tiles_w) * TW;
   };
-  bf16x8 pre[NLD];
-  auto load_patch = [&](int t) {         // chunk c of the patch image = 16-byte slot c % CH of patch position c / CH: lane-linear in LDS
+  // Buffer descriptors over the whole tensors (< 4 GB, checked by the launcher): a load past the end returns zeros - the padding - and a
+  // store past the end is dropped, so neither needs a branch.  With exec-masked branches around them hipcc cannot count the memory
+  // operations in flight and falls back to s_waitcnt vmcnt(0): at the loop head that waited out the previous tile's stores.
+  const unsigned xbytes = (unsigned)p.N * H * Wd * ROWB, ybytes = (unsigned)p.N * H * Wd * 128;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(X), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(Y, 0, ybytes, 0x00020000);
+  u32x4 pre[NLD];
+  // per-thread constants of its NLD chunks: row / column of the patch position and the byte offset of the chunk relative to the patch origin
+  int cpr[NLD], cpc[NLD];
+  unsigned crel[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int c = tid + 256 * j, pp = c / CH, s = c % CH;
+    cpr[j] = pp / PW - PLO; cpc[j] = pp % PW - PLO;
+    crel[j] = (unsigned)((cpr[j] * Wd + cpc[j]) * ROWB + (s << 4));
+  }
+  auto load_patch = [&](int t) {         // chunk c of the patch = 16-byte slot c % CH of patch position c / CH
     int n, h0, w0;
     origin(t, n, h0, w0);
-    const __bf16* img = X + (size_t)n * H * Wd * CI;
+    const unsigned base = (unsigned)((n * H + h0) * Wd + w0) * ROWB;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      const int c = tid + 256 * j, pp = c / CH, s = c % CH, pr = pp / PW, pc = pp - pr * PW;
-      const int ih = h0 - PLO + pr, iw = w0 - PLO + pc;
-      const bool ok = (NCH % 256 == 0 || c < NCH) && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)Wd;
-      bf16x8 v;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = (__bf16)0.f;
-      if (ok) v = *reinterpret_cast<const bf16x8*>(img + ((size_t)ih * Wd + iw) * CI + ((s ^ hc_swz<CI>(pp)) << 3));
-      pre[j] = v;
+      const bool ok = (unsigned)(h0 + cpr[j]) < (unsigned)H && (unsigned)(w0 + cpc[j]) < (unsigned)Wd;      // c >= NCH: loaded, never stored
+      // bit 31 sends a padding position past the end of the buffer (tensors < 2 GB) - arithmetic, not a select: hipcc turns `ok ? offset :
+      // past_the_end` into a branch around the offset arithmetic
+      pre[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, (base + crel[j]) | ((unsigned)!ok << 31), 0, 0);
     }
   };
   auto store_patch = [&]() {
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int c = tid + 256 * j;
-      if (NCH % 256 == 0 || c < NCH) *reinterpret_cast<bf16x8*>(Pl + c * 16) = pre[j];
+      if (NCH % 256 == 0 || c < NCH) *reinterpret_cast<u32x4*>(Pl + (c / CH) * PROWB + (c % CH) * 16) = pre[j];
     }
   };
   load_patch(cur);
   store_patch();
   __syncthreads();
+  HC_T(t_loop);
+  HC_ADD(0, t_begin, t_loop);
+#ifdef SV_HC_PROFILE
+  const long long wall_loop = wall_clock64();
+  int hc_tiles = 0;
+#endif
 
-  float s1[2][16], s2[2][16];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { s1[mb][j] = 0.f; s2[mb][j] = 0.f; }
+  // BatchNorm statistics: lane (h = kg, cp = ln) owns channels 2 cp, 2 cp + 1 over the positions of tile row 2 wave + h.  Per tile it sums
+  // the STORED bf16 values of its row from the staging image in a fixed order (fp32, <= 32 terms) and adds that to four double
+  // accumulators: which workgroup computes which tiles changes from run to run (run-time draw), the sums do not - beyond the order of
+  // double additions.  (Per-lane fp32 sums over all tiles of a workgroup, the first form, moved the batch mean by 1e-4 of itself from run to
+  // run: harmless beside bf16, but it made two identical training steps differ by 1e-2 in the stem's BatchNorm gradient.)
+  double sd[4] = {0.0, 0.0, 0.0, 0.0};   // sum / sum of squares of channel 2 cp, then of channel 2 cp + 1
   const int swa = hc_swz<CI>(ln);        // rows ln and 32 + ln of a tap's weight image share it (both forms of hc_swz have period <= 32)
 
   while (true) {
-    if (nxt >= 0) load_patch(nxt);
-    int drawn = 0;
-    if (tid == 0 && nxt >= 0) drawn = atomicAdd(ctr + xcd, 1);
+    int drawn;                           // thread 0 only, read behind the contraction (no initial value: a merge of two values at the end of
+    if (tid == 0) drawn = atomicAdd(ctr + xcd, nxt >= 0 ? 1 : 0);   // this branch would be a copy, i.e. a wait for the return right here)
 
+    HC_T(t0);
+    // The next patch goes out before the first MFMA (unconditionally: the last tile re-reads its own).  Spread over the MFMA loop the loads
+    // came out worse: hipcc's scheduler parked half of them behind the last MFMA, and their address arithmetic split the loop into blocks.
+    load_patch(nxt >= 0 ? nxt : cur);
+    __builtin_amdgcn_sched_barrier(0);
+    HC_T(t1);
     // ---- contraction: wave w owns tile rows 2 w, 2 w + 1 (two blocks of 32 positions) x 64 channels (two blocks of 32)
     f32x16 acc[2][2];
 #pragma unroll
@@ -126,32 +182,41 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloConvArgs p,
         for (int j = 0; j < 16; ++j) acc[mb][nb][j] = 0.f;
     // fragments of step (tap, 16-channel slice) + 1 are read while the 4 MFMAs of the step run (one wave per SIMD: nobody else hides the LDS)
     bf16x8 fa[2][2], fb[2][2];
-    auto frags = [&](int step, bf16x8* a, bf16x8* b) {
-      const int t = step / KS, ks = step - t * KS, kh = t / KW, kw = t - kh * KW, ch = 2 * ks + kg;
-      a[0] = *reinterpret_cast<const bf16x8*>(Wl + (t * 64 + ln) * ROWB + ((ch ^ swa) << 4));
-      a[1] = *reinterpret_cast<const bf16x8*>(Wl + (t * 64 + 32 + ln) * ROWB + ((ch ^ swa) << 4));
+    const char* pa = Wl + ln * ROWB;
+    const char* pq = Pl + (2 * wave * PW + ln) * PROWB + kg * 16;
+    int aoff[KS];
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const int pp = (2 * wave + nb + kh) * PW + ln + kw;
-        b[nb] = *reinterpret_cast<const bf16x8*>(Pl + pp * ROWB + ((ch ^ hc_swz<CI>(pp)) << 4));
-      }
+    for (int ks = 0; ks < KS; ++ks) aoff[ks] = ((2 * ks + kg) ^ swa) << 4;
+    auto frags = [&](int step, bf16x8* a, bf16x8* b) {
+      const int t = step / KS, ks = step - t * KS, kh = t / KW, kw = t - kh * KW;
+      a[0] = *reinterpret_cast<const bf16x8*>(pa + t * 64 * ROWB + aoff[ks]);
+      b[0] = *reinterpret_cast<const bf16x8*>(pq + (kh * PW + kw) * PROWB + ks * 32);
+      a[1] = *reinterpret_cast<const bf16x8*>(pa + (t * 64 + 32) * ROWB + aoff[ks]);
+      b[1] = *reinterpret_cast<const bf16x8*>(pq + ((kh + 1) * PW + kw) * PROWB + ks * 32);
     };
     frags(0, fa[0], fb[0]);
 #pragma unroll
     for (int step = 0; step < T * KS; ++step) {
       const int c = step & 1;
       if (step + 1 < T * KS) frags(step + 1, fa[c ^ 1], fb[c ^ 1]);
-      __builtin_amdgcn_sched_barrier(0);               // hipcc otherwise sinks the reads to their first use: the MFMA would wait out the LDS
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][1], fb[c][1], acc[1][1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      // hipcc otherwise sinks the reads to their first use (the MFMA would wait out the LDS): the four reads of the next step go out around
+      // the first MFMA of this one, three MFMAs (96 cycles) before the first of them is needed
+      if (step + 1 < T * KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (step + 1 < T * KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
     __syncthreads();                     // every wave is done reading the patch
+    HC_T(t2);
     if (nxt >= 0) store_patch();
     if (tid == 0) mbox[0] = (nxt >= 0 && drawn < csize) ? cbase + drawn : -1;
 
+    HC_T(t3);
     // ---- epilogue of `cur`: lane (ln, kg) holds, per block pair (mb, nb), position 32 nb + ln and channels 32 mb + 8 (j / 4) + 4 kg + j % 4
     int n, h0, w0;
     origin(cur, n, h0, w0);
@@ -159,7 +224,6 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloConvArgs p,
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const int q = nb * 32 + ln;
-      const float valid = (hr + nb < H && w0 + ln < Wd) ? 1.f : 0.f;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
@@ -168,46 +232,54 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloConvArgs p,
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             o[i] = (__bf16)acc[mb][nb][jg * 4 + i];
-            if (p.stats) {               // of what is stored (sv_epilogue.stats), as the gather engine's epilogue counts
-              const float v = (float)o[i], m = v * valid;
-              s1[mb][jg * 4 + i] += m; s2[mb][jg * 4 + i] += m * v;
-            }
           }
           *reinterpret_cast<bf16x4*>(Sl + q * 128 + (((mb * 4 + jg) ^ (q & 7)) << 4) + kg * 8) = o;
         }
       }
     }
-    __bf16* yimg = Y + (size_t)n * H * Wd * 64;
 #pragma unroll
     for (int itr = 0; itr < 8; ++itr) {  // 8 lanes = one 128-byte row; one instruction = 8 consecutive positions = 1 KB contiguous
       const int q = itr * 8 + (lane >> 3), c8 = lane & 7;
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(Sl + q * 128 + ((c8 ^ (q & 7)) << 4));
+      const u32x4 v = *reinterpret_cast<const u32x4*>(Sl + q * 128 + ((c8 ^ (q & 7)) << 4));
       const int row = hr + (q >> 5), col = w0 + (q & 31);
-      if (row < H && col < Wd) *reinterpret_cast<bf16x8*>(yimg + ((size_t)row * Wd + col) * 64 + c8 * 8) = v;
+      const unsigned off = ((unsigned)((n * H + row) * Wd + col) * 128 + c8 * 16) | ((unsigned)!(row < H && col < Wd) << 31);
+      __builtin_amdgcn_raw_buffer_store_b128(v, yr, off, 0, 0);
+    }
+    if (p.stats && hr + kg < H) {        // of what is stored (sv_epilogue.stats): row 2 wave + kg of the tile, columns inside the image
+      const int ncol = min(TW, Wd - w0);
+      float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+      const char* srow = Sl + kg * 32 * 128 + (ln & 3) * 4;
+#pragma unroll 8
+      for (int i = 0; i < ncol; ++i) {   // position q = 32 kg + i: its 16-byte slots are XOR-swizzled by q & 7 = i & 7
+        const unsigned u = *reinterpret_cast<const unsigned*>(srow + i * 128 + ((((ln >> 2) ^ i) & 7) << 4));
+        const float v0 = __uint_as_float(u << 16), v1 = __uint_as_float(u & 0xffff0000u);
+        a0 += v0; b0 += v0 * v0; a1 += v1; b1 += v1 * v1;
+      }
+      sd[0] += (double)a0; sd[1] += (double)b0; sd[2] += (double)a1; sd[3] += (double)b1;
     }
     __syncthreads();                     // the next patch and the mailbox are complete
+    HC_T(t4);
+#ifdef SV_HC_PROFILE
+    ++hc_tiles;
+#endif
+    HC_ADD(2, t1, t2); HC_ADD(3, t2, t3); HC_ADD(4, t3, t4);
     if (nxt < 0) break;
     cur = nxt;
     nxt = __builtin_amdgcn_readfirstlane(mbox[0]);      // thread 0 posts again behind the next barrier, which needs everyone past this read
   }
 
-  if (p.stats) {    // lanes that share kg (32 positions each) -> lanes 0 and 32 -> double atomics into a slot image
-    double* st = p.stats + (size_t)((blockIdx.x * 4 + wave) % SV_BN_SLOTS) * 128;
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float a = s1[mb][j], b = s2[mb][j];
-        a = lane_step_add<1>(a); a = lane_step_add<2>(a); a = lane_step_add<4>(a); a = lane_step_add<8>(a); a = lane_step_add<16>(a);
-        b = lane_step_add<1>(b); b = lane_step_add<2>(b); b = lane_step_add<4>(b); b = lane_step_add<8>(b); b = lane_step_add<16>(b);
-        if (ln == 0) {
-          const int co = mb * 32 + 8 * (j >> 2) + 4 * kg + (j & 3);
-          atomicAdd(st + co, (double)a);
-          atomicAdd(st + 64 + co, (double)b);
-        }
-      }
-    }
+  HC_T(t_post);
+  if (p.stats) {    // 256 double atomics per wave into a slot image (full-wave instructions: 4 per wave)
+    double* st = p.stats + (size_t)((blockIdx.x * 8 + wave * 2 + kg) % SV_BN_SLOTS) * 128;
+    atomicAdd(st + 2 * ln, sd[0]);
+    atomicAdd(st + 64 + 2 * ln, sd[1]);
+    atomicAdd(st + 2 * ln + 1, sd[2]);
+    atomicAdd(st + 64 + 2 * ln + 1, sd[3]);
   }
+#ifdef SV_HC_PROFILE
+  if (tid == 0) { hc_wg[blockIdx.x][0] = wall_begin; hc_wg[blockIdx.x][1] = wall_loop; hc_wg[blockIdx.x][2] = wall_clock64(); hc_wg[blockIdx.x][3] = hc_tiles; }
+  if (blockIdx.x == 0 && tid == 0) { hc_prof[6] += wall_clock64() - wall_begin; hc_prof[7] += clock64() - t_begin; hc_prof[1] += clock64() - t_post; hc_prof[5] = t_post - t_loop; }   // 100 MHz ticks / shader cycles
+#endif
   if (tid == 0) finish();
 }
 
@@ -225,6 +297,7 @@ int conv_halo_launch(const HaloConvArgs& a, int kind, hipStream_t stream) {
   const int tiles_h = cdiv(a.H, 8), tiles_w = cdiv(a.W, 32);
   const long long nt = (long long)a.N * tiles_h * tiles_w;
   const int mode = halo_mode().load(std::memory_order_relaxed);
+  if ((long long)a.N * a.H * a.W * 128 >= (1ll << 31)) return 0;          // buffer descriptors: 32-bit byte offsets, bit 31 = "outside"
   if ((mode == 1 && nt < 256) || nt >= (1ll << 30)) return 0;   // fewer tiles than CUs: 72 KB of weights per workgroup for one tile each
   int* ctr = tile_draw_counters();
   if (!ctr) return 0;
@@ -246,3 +319,13 @@ extern "C" int sv_set_conv_halo(int mode) {
 }
 extern "C" long long sv_conv_halo_launches(void) { return sv::halo_launches.load(std::memory_order_relaxed); }
 extern "C" int sv_conv_halo_mode(void) { return sv::halo_mode().load(std::memory_order_relaxed); }
+#ifdef SV_HC_PROFILE
+extern "C" int sv_conv_halo_prof_wg(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sv::hc_wg), sizeof(long long) * 1024) == hipSuccess ? 0 : -1;
+}
+extern "C" int sv_conv_halo_prof(long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sv::hc_prof), sizeof(long long) * 8) != hipSuccess) return -1;
+  if (reset) { long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sv::hc_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
