@@ -10,7 +10,8 @@
 //     prefetched into registers while the previous tile is contracted (one buffer: the second would not fit beside the weights),
 //   * all taps run from that patch: per tap and 16 channels a wave reads 2 weight fragments and 2 patch fragments (ds_read_b128, XOR-swizzled:
 //     conflict-free) for 4 v_mfma_f32_32x32x16_bf16 - weights are the A operand, so a lane ends up with CHANNELS of one position,
-//   * the 64 x 64 result of a wave turns through a private 8 KB LDS patch into 16-byte lanes: one store instruction = 8 whole 128-byte rows,
+//   * the 64 x 64 result of a wave turns, one tile row at a time, through a private 4 KB LDS image into 16-byte lanes: one store instruction =
+//     8 whole 128-byte rows,
 //   * BatchNorm statistics: per tile a lane sums two channels of one tile row from the staging image (fixed order), then adds into four
 //     double registers that live across all tiles of the workgroup: 256 double atomics per wave per LAUNCH.
 // Tiles are drawn at run time from per-XCD counters (a static share stalls the launch when another stream's kernel holds a CU: DESIGN 4b).
@@ -24,7 +25,7 @@ namespace sv {
 
 #ifdef SV_HC_PROFILE   // cycles of workgroup 0 / thread 0 per phase: [0] preamble, [1] patch issue, [2] contraction, [3] patch store, [4] epilogue, [5] tiles
 __device__ long long hc_prof[8];
-__device__ long long hc_wg[256][4];   // per workgroup: wall-clock (100 MHz) at start / loop start / end, tiles
+__device__ long long hc_wg[512][4];   // per workgroup: wall-clock (100 MHz) at start / loop start / end, tiles
 #define HC_T(v) const long long v = clock64()
 #define HC_ADD(i, a, b) if (blockIdx.x == 0 && tid == 0) hc_prof[i] += (b) - (a)
 #else
@@ -40,8 +41,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // 32-byte rows: bit 3 of r (rows r, r + 8 share a slot pair, the XOR sends them to different halves of it)
 template <int CI> __device__ __forceinline__ int hc_swz(int r) { return CI == 64 ? ((r >> 1) & 7) : ((r >> 3) & 1); }
 
-template <int CI, int KH, int KW, int PLO>
-__global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloConvArgs p, int tiles_h, int tiles_w, int ntiles, int* __restrict__ ctr) {
+template <int CI, int KH, int KW, int PLO, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_halo_kernel(const HaloConvArgs p, int tiles_h, int tiles_w, int ntiles, int* __restrict__ ctr) {
   constexpr int TH = 8, TW = 32, T = KH * KW, PH = TH + KH - 1, PW = TW + KW - 1, NPOS = PH * PW;
   constexpr int CH = CI / 8, ROWB = CI * 2, KS = CI / 16;
   constexpr int NCH = NPOS * CH, NLD = (NCH + 255) / 256;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloConvArgs p,
   // between the MFMAs.  The weight image cannot afford the padding (82,944 + 48,960 + 32,768 B > 160 KB) and keeps the XOR, whose four
   // variants per lane are loop constants.
   constexpr int PROWB = ROWB + 16;
-  constexpr int W_BYTES = T * 64 * ROWB, PATCH_BYTES = (NPOS * PROWB + 127) / 128 * 128, STAGE_BYTES = 4 * 8192;
+  constexpr int W_BYTES = T * 64 * ROWB, PATCH_BYTES = (NPOS * PROWB + 127) / 128 * 128, STAGE_BYTES = 4 * 4096;
   constexpr int WCH = T * 64 * CH;
   __shared__ __attribute__((aligned(1024))) char smem[W_BYTES + PATCH_BYTES + STAGE_BYTES + 16];
   const __bf16* __restrict__ X = static_cast<const __bf16*>(p.x);
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloConvArgs p,
 #endif
   char* Wl = smem;
   char* Pl = smem + W_BYTES;
-  char* Sl = smem + W_BYTES + PATCH_BYTES + wave * 8192;
+  char* Sl = smem + W_BYTES + PATCH_BYTES + wave * 4096;
   int* mbox = reinterpret_cast<int*>(smem + W_BYTES + PATCH_BYTES + STAGE_BYTES);
 
   // ---- tile scheduler (gemm_wide_kernel's: 8 contiguous chunks of the tile space, one per XCD; ctr[8] counts finished workgroups)
@@ -134,7 +135,11 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloConvArgs p,
       const bool ok = (unsigned)(h0 + cpr[j]) < (unsigned)H && (unsigned)(w0 + cpc[j]) < (unsigned)Wd;      // c >= NCH: loaded, never stored
       // bit 31 sends a padding position past the end of the buffer (tensors < 2 GB) - arithmetic, not a select: hipcc turns `ok ? offset :
       // past_the_end` into a branch around the offset arithmetic
+#ifdef SV_HC_PROBE_L2      // timing probe: every patch comes from one 1 MB window (L2 hits) - what the HBM latency of the real loads costs
+      pre[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, ((base + crel[j]) & 0xffff0u) | ((unsigned)!ok << 31), 0, 0);
+#else
       pre[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, (base + crel[j]) | ((unsigned)!ok << 31), 0, 0);
+#endif
     }
   };
   auto store_patch = [&]() {
@@ -221,42 +226,53 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloConvArgs p,
     int n, h0, w0;
     origin(cur, n, h0, w0);
     const int hr = h0 + 2 * wave;
+    const int ncol = min(TW, Wd - w0);
+    f32x2 sa = {0.f, 0.f}, sb = {0.f, 0.f};
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const int q = nb * 32 + ln;
+    for (int nb = 0; nb < 2; ++nb) {     // one tile row (32 positions x 64 channels = 4 KB) at a time through the wave's staging image
+      const int row = hr + nb;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
         for (int jg = 0; jg < 4; ++jg) {
           bf16x4 o;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            o[i] = (__bf16)acc[mb][nb][jg * 4 + i];
+          for (int i = 0; i < 4; ++i) o[i] = (__bf16)acc[mb][nb][jg * 4 + i];
+          *reinterpret_cast<bf16x4*>(Sl + ln * 128 + (((mb * 4 + jg) ^ (ln & 7)) << 4) + kg * 8) = o;
+        }
+      }
+#pragma unroll
+      for (int itr = 0; itr < 4; ++itr) {  // 8 lanes = one 128-byte row; one instruction = 8 consecutive positions = 1 KB contiguous
+        const int q = itr * 8 + (lane >> 3), c8 = lane & 7, col = w0 + q;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(Sl + q * 128 + ((c8 ^ (q & 7)) << 4));
+        const unsigned off = ((unsigned)((n * H + row) * Wd + col) * 128 + c8 * 16) | ((unsigned)!(row < H && col < Wd) << 31);
+#ifdef SV_HC_PROBE_NOSTORE  // timing probe: no output stream
+        __builtin_amdgcn_raw_buffer_store_b128(v, yr, off | 0x80000000u, 0, 0);
+#else
+        __builtin_amdgcn_raw_buffer_store_b128(v, yr, off, 0, 0);
+#endif
+      }
+      if (p.stats && row < H) {          // of what is stored (sv_epilogue.stats): lane (kg, cp = ln) takes positions 16 kg .. 16 kg + 15 of the row
+        const char* srow = Sl + kg * 16 * 128 + (ln & 3) * 4;
+        if (ncol == TW) {                // packed fp32 pairs: (channel 2 cp, channel 2 cp + 1) per instruction
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { // position q = 16 kg + i: its 16-byte slots are XOR-swizzled by q & 7 = i & 7
+            const unsigned u = *reinterpret_cast<const unsigned*>(srow + i * 128 + ((((ln >> 2) ^ i) & 7) << 4));
+            const f32x2 v = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+            sa += v; sb += v * v;
           }
-          *reinterpret_cast<bf16x4*>(Sl + q * 128 + (((mb * 4 + jg) ^ (q & 7)) << 4) + kg * 8) = o;
+        } else {                         // a tile cut by the right image edge
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const unsigned u = *reinterpret_cast<const unsigned*>(srow + i * 128 + ((((ln >> 2) ^ i) & 7) << 4));
+            const float m = 16 * kg + i < ncol ? 1.f : 0.f;
+            const f32x2 v = {__uint_as_float(u << 16) * m, __uint_as_float(u & 0xffff0000u) * m};
+            sa += v; sb += v * v;
+          }
         }
       }
     }
-#pragma unroll
-    for (int itr = 0; itr < 8; ++itr) {  // 8 lanes = one 128-byte row; one instruction = 8 consecutive positions = 1 KB contiguous
-      const int q = itr * 8 + (lane >> 3), c8 = lane & 7;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(Sl + q * 128 + ((c8 ^ (q & 7)) << 4));
-      const int row = hr + (q >> 5), col = w0 + (q & 31);
-      const unsigned off = ((unsigned)((n * H + row) * Wd + col) * 128 + c8 * 16) | ((unsigned)!(row < H && col < Wd) << 31);
-      __builtin_amdgcn_raw_buffer_store_b128(v, yr, off, 0, 0);
-    }
-    if (p.stats && hr + kg < H) {        // of what is stored (sv_epilogue.stats): row 2 wave + kg of the tile, columns inside the image
-      const int ncol = min(TW, Wd - w0);
-      float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
-      const char* srow = Sl + kg * 32 * 128 + (ln & 3) * 4;
-#pragma unroll 8
-      for (int i = 0; i < ncol; ++i) {   // position q = 32 kg + i: its 16-byte slots are XOR-swizzled by q & 7 = i & 7
-        const unsigned u = *reinterpret_cast<const unsigned*>(srow + i * 128 + ((((ln >> 2) ^ i) & 7) << 4));
-        const float v0 = __uint_as_float(u << 16), v1 = __uint_as_float(u & 0xffff0000u);
-        a0 += v0; b0 += v0 * v0; a1 += v1; b1 += v1 * v1;
-      }
-      sd[0] += (double)a0; sd[1] += (double)b0; sd[2] += (double)a1; sd[3] += (double)b1;
-    }
+    if (p.stats) { sd[0] += (double)sa[0]; sd[1] += (double)sb[0]; sd[2] += (double)sa[1]; sd[3] += (double)sb[1]; }
     __syncthreads();                     // the next patch and the mailbox are complete
     HC_T(t4);
 #ifdef SV_HC_PROFILE
@@ -303,9 +319,9 @@ int conv_halo_launch(const HaloConvArgs& a, int kind, hipStream_t stream) {
   if (!ctr) return 0;
   const int ntiles = (int)nt;
   if (kind == 0)
-    hipLaunchKernelGGL((conv_halo_kernel<64, 3, 3, 1>), dim3(256), dim3(256), 0, stream, a, tiles_h, tiles_w, ntiles, ctr);
-  else
-    hipLaunchKernelGGL((conv_halo_kernel<16, 4, 4, 2>), dim3(256), dim3(256), 0, stream, a, tiles_h, tiles_w, ntiles, ctr);
+    hipLaunchKernelGGL((conv_halo_kernel<64, 3, 3, 1, 1>), dim3(256), dim3(256), 0, stream, a, tiles_h, tiles_w, ntiles, ctr);
+  else   // 32 KB of weights + 18 KB patch + 16 KB staging: two workgroups per CU - one's epilogue runs under the other's MFMAs
+    hipLaunchKernelGGL((conv_halo_kernel<16, 4, 4, 2, 2>), dim3(512), dim3(256), 0, stream, a, tiles_h, tiles_w, ntiles, ctr);
   halo_launches.fetch_add(1, std::memory_order_relaxed);
   return 1;
 }
@@ -321,7 +337,7 @@ extern "C" long long sv_conv_halo_launches(void) { return sv::halo_launches.load
 extern "C" int sv_conv_halo_mode(void) { return sv::halo_mode().load(std::memory_order_relaxed); }
 #ifdef SV_HC_PROFILE
 extern "C" int sv_conv_halo_prof_wg(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sv::hc_wg), sizeof(long long) * 1024) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sv::hc_wg), sizeof(long long) * 2048) == hipSuccess ? 0 : -1;
 }
 extern "C" int sv_conv_halo_prof(long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sv::hc_prof), sizeof(long long) * 8) != hipSuccess) return -1;
