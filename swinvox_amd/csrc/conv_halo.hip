@@ -15,6 +15,9 @@
 //   * BatchNorm statistics: per tile a lane sums two channels of one tile row from the staging image (fixed order), then adds into four
 //     double registers that live across all tiles of the workgroup: 256 double atomics per wave per LAUNCH.
 // Tiles are drawn at run time from per-XCD counters (a static share stalls the launch when another stream's kernel holds a CU: DESIGN 4b).
+// (Going on with the next XCD's chunk once the own one is exhausted was built and measured: the XCDs finish up to 14 % apart, yet the launch
+// got 10 % SLOWER on the same box, 156 -> 171 us and 359 -> 396 us - the stolen tiles' halo rows are in another L2 and the draw loop sits on
+// the path between the two barriers.  Not kept.)
 // What bounds it then: the output stream (kind 0: 205 MB in + 205 MB out per launch at 512 images).
 #include "common.h"
 #include "conv_halo.h"
