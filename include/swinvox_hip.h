@@ -191,6 +191,16 @@ int sv_bn_finalize(const double* sums, long long count, const float* gamma, cons
  * in 12-wide rows therefore never needs a separate zero fill (swinvox_amd/models/merger.py relies on this). */
 int sv_scale_shift_act(const void* x, int ldx, const float* scale, const float* shift, const void* residual, int ldr,
                        void* y, int ldy, long long M, int C, int act, float slope, int act_dtype, void* stream);
+/* ResNet stem: BatchNorm + activation + MaxPool2d(3, stride 2, padding 1) in one pass over the convolution's output x [N, H, W, C] (rows of exactly C
+ * elements, C % 4 == 0, 256 % (C / 4) == 0): pooled / idx [N, (H+1)/2, (W+1)/2, C] (idx: arg-max tap 0..8 per element, first maximum in scan order).
+ * The normalised activation is never stored.  sv_bn_maxpool_bwd: gradient of the pooled map -> dx (w.r.t. x) with the pool's backward computed on the
+ * fly inside both passes of the BatchNorm backward; dgamma / dbeta +=; sums_ws: sv_bn_bwd_workspace_doubles(C) doubles, zero on entry.
+ * Replaces sv_scale_shift_act + sv_maxpool2d_fwd and sv_maxpool2d_bwd + sv_bn_bwd of reference models/encoder.py:22-23 (resnet50 bn1 / relu / maxpool). */
+int sv_bn_act_maxpool_fwd(const void* x, const float* scale, const float* shift, void* pooled, void* idx, int N, int H, int W, int C,
+                          int act, float slope, int act_dtype, void* stream);
+int sv_bn_maxpool_bwd(const void* dpooled, const void* idx, const void* x, const float* gamma, const float* save_mean, const float* save_rstd,
+                      const float* fwd_scale, const float* fwd_shift, int N, int H, int W, int C, int act, float slope, int training,
+                      void* dx, float* dgamma, float* dbeta, double* sums_ws, int act_dtype, void* stream);
 size_t sv_bn_bwd_workspace_doubles(int C);   /* size of sums_ws below */
 int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const void* x, int ldx, const float* gamma,
               const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,

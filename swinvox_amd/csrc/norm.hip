@@ -872,6 +872,179 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __rest
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// ResNet stem: BatchNorm + ReLU + MaxPool2d(3, stride 2, padding 1) (reference models/encoder.py:22-23: torchvision resnet50's bn1 / relu /
+// maxpool) without the 112 x 112 x 64 activation in between - at 512 images that tensor is 822 MB, written by the normalisation pass, read by
+// the pool, written again (as its gradient) by the pool's backward and read twice by the BatchNorm backward.
+//   forward : pooled[o] = max over the window of relu(scale * y + shift) (each value rounded to the storage type first, as the separate pass
+//             stored it), arg-max tap kept (first maximum in scan order, as torch) - reads y once, writes the 56 x 56 map + 1 byte per element;
+//   backward: dz[i] = sum over the <= 2 x 2 windows that contain i of dpooled[o] * [argmax(o) == i] (the pool's gather form), computed on the
+//             fly in BOTH passes of the BatchNorm backward (reduce: sums of dz' and dz' * xhat; apply: dy = k1 dz' - k2 - k3 y): neither dz nor
+//             the activation is ever stored.
+// A thread owns 4 adjacent channels; a workgroup walks whole image rows (no per-position divisions).
+// ------------------------------------------------------------------------------------------------
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_act_maxpool_fwd_kernel(const AT* __restrict__ x, const float* __restrict__ fsc, const float* __restrict__ fsh,
+                                                                 AT* __restrict__ y, uint8_t* __restrict__ idx, int N, int H, int W, int C, int Ho, int Wo,
+                                                                 int act, float slope) {
+  const int cv = C >> 2;
+  const long long total = (long long)N * Ho * Wo * cv;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cv) * 4; long long t = i / cv;
+    const int ow = (int)(t % Wo); t /= Wo; const int oh = (int)(t % Ho); const int n = (int)(t / Ho);
+    const float4 sc = *reinterpret_cast<const float4*>(fsc + c), sh = *reinterpret_cast<const float4*>(fsh + c);
+    const float s_[4] = {sc.x, sc.y, sc.z, sc.w}, h_[4] = {sh.x, sh.y, sh.z, sh.w};
+    float best[4] = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+    int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          const float4 q = ld4f(x + (((size_t)n * H + ih) * W + iw) * C + c);
+          const float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float z = (float)(AT)apply_act(__fmaf_rn(v[j], s_[j], h_[j]), act, slope);   // what scale_shift_act would have stored
+            if (z > best[j]) { best[j] = z; bi[j] = kh * 3 + kw; }
+          }
+        }
+      }
+    const size_t o = (((size_t)n * Ho + oh) * Wo + ow) * C + c;
+    st4f(y + o, make_float4(best[0], best[1], best[2], best[3]));
+    *reinterpret_cast<uchar4*>(idx + o) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+  }
+}
+
+// The pool's data gradient for the 2 x 2 input block (2a .. 2a + 1, 2b .. 2b + 1), channels c .. c + 3: the block lies in the windows (a, b),
+// (a, b + 1), (a + 1, b), (a + 1, b + 1) only, so four pooled gradients + their arg-max taps (tap = 3 kh + kw, input = 2 o - 1 + k) serve four
+// positions - and all four loads go out together (the per-position gather form of maxpool2d_bwd_kernel re-reads each pooled element 2.25
+// times behind data-dependent loop bounds: 1.57 ms for the two passes against 1.51 for the separate kernels).  d[p][j]: p = 2 * dy + dx.
+template <typename AT>
+__device__ __forceinline__ void pool_block_grad(const AT* __restrict__ dmp, const uint8_t* __restrict__ idx, int n, int a, int b, int c, int C, int Ho, int Wo,
+                                                float d[4][4]) {
+  const size_t o00 = (((size_t)n * Ho + a) * Wo + b) * C + c;
+  const bool vb = b + 1 < Wo, va = a + 1 < Ho;
+  const size_t o01 = vb ? o00 + C : o00, o10 = va ? o00 + (size_t)Wo * C : o00, o11 = (va && vb) ? o00 + (size_t)Wo * C + C : o00;
+  const float4 g00 = ld4f(dmp + o00), g01 = ld4f(dmp + o01), g10 = ld4f(dmp + o10), g11 = ld4f(dmp + o11);
+  const uchar4 i00 = *reinterpret_cast<const uchar4*>(idx + o00), i01 = *reinterpret_cast<const uchar4*>(idx + o01);
+  const uchar4 i10 = *reinterpret_cast<const uchar4*>(idx + o10), i11 = *reinterpret_cast<const uchar4*>(idx + o11);
+  const float G[4][4] = {{g00.x, g00.y, g00.z, g00.w}, {g01.x, g01.y, g01.z, g01.w}, {g10.x, g10.y, g10.z, g10.w}, {g11.x, g11.y, g11.z, g11.w}};
+  const int I0[4] = {i00.x, i00.y, i00.z, i00.w};
+  const int I1[4] = {vb ? i01.x : 255, vb ? i01.y : 255, vb ? i01.z : 255, vb ? i01.w : 255};
+  const int I2[4] = {va ? i10.x : 255, va ? i10.y : 255, va ? i10.z : 255, va ? i10.w : 255};
+  const int I3[4] = {(va && vb) ? i11.x : 255, (va && vb) ? i11.y : 255, (va && vb) ? i11.z : 255, (va && vb) ? i11.w : 255};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    d[0][j] = I0[j] == 4 ? G[0][j] : 0.f;
+    d[1][j] = (I0[j] == 5 ? G[0][j] : 0.f) + (I1[j] == 3 ? G[1][j] : 0.f);
+    d[2][j] = (I0[j] == 7 ? G[0][j] : 0.f) + (I2[j] == 1 ? G[2][j] : 0.f);
+    d[3][j] = (I0[j] == 8 ? G[0][j] : 0.f) + (I1[j] == 6 ? G[1][j] : 0.f) + (I2[j] == 2 ? G[2][j] : 0.f) + (I3[j] == 0 ? G[3][j] : 0.f);
+  }
+}
+
+// pass 1: G = C / 4 column groups x 256 / G block lanes; blockIdx.x owns image-row PAIRS [blockIdx.x * rpb, +rpb) of the N * Ho pairs
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const AT* __restrict__ dmp, const uint8_t* __restrict__ idx, const AT* __restrict__ x,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ fsc, const float* __restrict__ fsh, double* __restrict__ sums,
+                                                                 int N, int H, int W, int C, int Ho, int Wo, int act, float slope, int rpb) {
+  __shared__ double red[256][9];
+  const int G = C >> 2, gq = threadIdx.x % G, rl = threadIdx.x / G, RL = 256 / G, c = gq * 4;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  if (rl < RL) {
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 sc = *reinterpret_cast<const float4*>(fsc + c), sh = *reinterpret_cast<const float4*>(fsh + c);
+    const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w}, s_[4] = {sc.x, sc.y, sc.z, sc.w}, h_[4] = {sh.x, sh.y, sh.z, sh.w};
+    const float neg = act == SV_ACT_LRELU ? slope : 0.f;
+    const int rp0 = blockIdx.x * rpb, rp1 = min(rp0 + rpb, N * Ho);
+    for (int rp = rp0; rp < rp1; ++rp) {
+      const int n = rp / Ho, a = rp - n * Ho;
+      float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};      // one row pair per lane in fp32 (<= 4 Wo / RL terms), then double
+      for (int b = rl; b < Wo; b += RL) {
+        float d[4][4];
+        pool_block_grad(dmp, idx, n, a, b, c, C, Ho, Wo, d);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int ih = 2 * a + (p >> 1), iw = 2 * b + (p & 1);
+          if (ih < H && iw < W) {
+            const float4 xv = ld4f(x + (((size_t)n * H + ih) * W + iw) * C + c);
+            const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float dd = d[p][j];
+              if (act != SV_ACT_NONE) dd *= __fmaf_rn(xx[j], s_[j], h_[j]) > 0.f ? 1.f : neg;
+              t1[j] += dd; t2[j] += dd * (xx[j] - mm[j]) * rr[j];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] += (double)t1[j]; s2[j] += (double)t2[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][4 + j] = s2[j]; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 8 * G; t += 256) {
+    const int q = t >> 3, k = t & 7;
+    double acc = 0.0;
+    for (int l = 0; l < RL; ++l) acc += red[l * G + q][k];
+    atomicAdd(sums + (size_t)(blockIdx.x % BN_BWD_SLOTS) * 2 * C + (k < 4 ? 0 : C) + q * 4 + (k & 3), acc);
+  }
+}
+
+// pass 2: dx = k1 dz' - k2 - k3 x (double coefficients: the mean-removal terms must cancel to rounding), dz' gathered again
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const AT* __restrict__ dmp, const uint8_t* __restrict__ idx, const AT* __restrict__ x,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ fsc, const float* __restrict__ fsh, const double* __restrict__ sums,
+                                                                AT* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo, int act, float slope,
+                                                                int training, int rpb) {
+  const int G = C >> 2, gq = threadIdx.x % G, rl = threadIdx.x / G, RL = 256 / G, c = gq * 4;
+  if (rl >= RL) return;
+  sums += (size_t)BN_BWD_SLOTS * 2 * C;     // the folded image (bn_bwd_fold_kernel)
+  double k1[4], k2[4], k3[4];
+  float s_[4], h_[4];
+  const double invM = 1.0 / ((double)N * H * W);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double gm = gamma[c + j], rs = rstd[c + j], mu = mean[c + j];
+    k1[j] = gm * rs;
+    if (training) { const double sa = sums[c + j] * invM, sb = sums[C + c + j] * invM; k3[j] = gm * rs * sb * rs; k2[j] = gm * rs * sa - k3[j] * mu; }
+    else { k2[j] = 0.0; k3[j] = 0.0; }
+    s_[j] = fsc[c + j]; h_[j] = fsh[c + j];
+  }
+  const float neg = act == SV_ACT_LRELU ? slope : 0.f;
+  const int rp0 = blockIdx.x * rpb, rp1 = min(rp0 + rpb, N * Ho);
+  for (int rp = rp0; rp < rp1; ++rp) {
+    const int n = rp / Ho, a = rp - n * Ho;
+    for (int b = rl; b < Wo; b += RL) {
+      float d[4][4];
+      pool_block_grad(dmp, idx, n, a, b, c, C, Ho, Wo, d);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int ih = 2 * a + (p >> 1), iw = 2 * b + (p & 1);
+        if (ih < H && iw < W) {
+          const size_t o = (((size_t)n * H + ih) * W + iw) * C + c;
+          const float4 xv = ld4f(x + o);
+          const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+          float out[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float dd = d[p][j];
+            if (act != SV_ACT_NONE) dd *= __fmaf_rn(xx[j], s_[j], h_[j]) > 0.f ? 1.f : neg;
+            out[j] = (float)(k1[j] * (double)dd - k2[j] - k3[j] * (double)xx[j]);
+          }
+          st4f(dx + o, make_float4(out[0], out[1], out[2], out[3]));
+        }
+      }
+    }
+  }
+}
+
 }  // namespace sv
 
 using namespace sv;
@@ -1058,6 +1231,50 @@ extern "C" int sv_scale_shift_act_signs(const void* x, int ldx, const float* sca
                                         void* y, int ldy, long long M, int C, int act, float slope, void* signs, int act_dtype, void* stream) {
   SV_REQUIRE(signs, "scale_shift_act_signs: null sign buffer");
   return scale_shift_act_impl(x, ldx, scale, shift, residual, ldr, y, ldy, M, C, act, slope, static_cast<unsigned long long*>(signs), act_dtype, stream);
+}
+
+// ---- ResNet stem, fused with its max-pool (kernels above).  x = the convolution's output [N, H, W, C] (rows of exactly C elements, C % 4 == 0,
+// C <= 256 with 256 % (C / 4) == 0), pooled / idx = [N, Ho, Wo, C] with Ho = (H + 1) / 2, Wo = (W + 1) / 2 (kernel 3, stride 2, padding 1).
+static bool bn_pool_shape_ok(int N, int H, int W, int C) {
+  return N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && (long long)N * H * W * C < (1ll << 40);
+}
+extern "C" int sv_bn_act_maxpool_fwd(const void* x, const float* scale, const float* shift, void* pooled, void* idx, int N, int H, int W, int C,
+                                     int act, float slope, int act_dtype, void* stream) {
+  SV_REQUIRE(x && scale && shift && pooled && idx && bn_pool_shape_ok(N, H, W, C), "bn_act_maxpool_fwd: bad arguments (N=%d H=%d W=%d C=%d)", N, H, W, C);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_REQUIRE(aligned4(act_dtype, x, pooled, nullptr, nullptr, nullptr) && (((uintptr_t)scale | (uintptr_t)shift) & 15) == 0 && ((uintptr_t)idx & 3) == 0,
+             "bn_act_maxpool_fwd: misaligned buffers");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  long long blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384;
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(bn_act_maxpool_fwd_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const AT*>(x),
+                                                scale, shift, static_cast<AT*>(pooled), static_cast<uint8_t*>(idx), N, H, W, C, Ho, Wo, act, slope););
+  return check_launch("sv_bn_act_maxpool_fwd");
+}
+/* dpooled [N, Ho, Wo, C] + idx -> dx [N, H, W, C] (gradient w.r.t. the BatchNorm input x), dgamma / dbeta += ; sums_ws as sv_bn_bwd */
+extern "C" int sv_bn_maxpool_bwd(const void* dpooled, const void* idx, const void* x, const float* gamma, const float* save_mean, const float* save_rstd,
+                                 const float* fwd_scale, const float* fwd_shift, int N, int H, int W, int C, int act, float slope, int training,
+                                 void* dx, float* dgamma, float* dbeta, double* sums_ws, int act_dtype, void* stream) {
+  SV_REQUIRE(dpooled && idx && x && gamma && save_mean && save_rstd && fwd_scale && fwd_shift && dx && dgamma && dbeta && sums_ws && bn_pool_shape_ok(N, H, W, C),
+             "bn_maxpool_bwd: bad arguments (N=%d H=%d W=%d C=%d)", N, H, W, C);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_REQUIRE(aligned4(act_dtype, dpooled, x, dx, nullptr, nullptr) && (((uintptr_t)save_mean | (uintptr_t)save_rstd | (uintptr_t)fwd_scale | (uintptr_t)fwd_shift) & 15) == 0 &&
+             ((uintptr_t)idx & 3) == 0, "bn_maxpool_bwd: misaligned buffers");
+  hipStream_t s = (hipStream_t)stream;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long long rows = (long long)N * Ho;     // image-row pairs
+  SV_REQUIRE(rows < (1ll << 31), "bn_maxpool_bwd: more than 2^31 image rows");
+  int rpb = (int)((rows + 2047) / 2048); if (rpb < 1) rpb = 1;
+  const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
+  int rpa = (int)((rows + 8191) / 8192); if (rpa < 1) rpa = 1;
+  const unsigned na = (unsigned)((rows + rpa - 1) / rpa);
+  SV_DISPATCH_ACT(act_dtype,
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<AT>, dim3(nb), dim3(256), 0, s, static_cast<const AT*>(dpooled), static_cast<const uint8_t*>(idx), static_cast<const AT*>(x),
+                       save_mean, save_rstd, fwd_scale, fwd_shift, sums_ws, N, H, W, C, Ho, Wo, act, slope, rpb);
+    hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<AT>, dim3(na), dim3(256), 0, s, static_cast<const AT*>(dpooled), static_cast<const uint8_t*>(idx), static_cast<const AT*>(x),
+                       gamma, save_mean, save_rstd, fwd_scale, fwd_shift, sums_ws, static_cast<AT*>(dx), N, H, W, C, Ho, Wo, act, slope, training, rpa););
+  return check_launch("sv_bn_maxpool_bwd");
 }
 
 extern "C" size_t sv_bn_bwd_workspace_doubles(int C) { return (size_t)(BN_BWD_SLOTS + 1) * 2 * C + 2; }

@@ -131,6 +131,8 @@ class Encoder(HipModule):
         return wp
 
     def _stem_fwd(self, images, I, tr):
+        """stem convolution + BatchNorm + ReLU + max-pool -> the 56 x 56 x 64 map.  Fused form (default, ops.set_stem_fused): the 112 x 112 x 64
+        activation between BatchNorm and pool is never stored (sv_bn_act_maxpool_fwd), nor is its gradient (sv_bn_maxpool_bwd)."""
         x16 = empty(I * 112 * 112, 16, like=images)                       # [.., (sy, sx, c)], channel 3 of every (sy, sx) group = 0
         call("sv_stem_space_to_depth", ptr(images), ptr(x16), I)
         sp, bn, M = self._stem_spec, self.resnet[1], I * 112 * 112
@@ -138,15 +140,31 @@ class Encoder(HipModule):
         st = BatchNormState(bn, M, tr)
         sp.forward(x16, I, (1, 112, 112), self._stem_pack(), y, stats=st.sums)
         st.finalize()
-        z = empty(M, 64, like=x16)
-        st.apply(y, 64, z, 64, ACT_RELU, 0.0)
-        return z, (1, 112, 112), (x16, y, st, M, I)
+        mp = empty(I * 56 * 56, 64, like=x16)
+        idx = torch.empty(I * 56 * 56 * 64, dtype=torch.uint8, device=x16.device)
+        fused = ops.stem_fused_enabled()
+        if fused:
+            st.probe(y, 64)
+            call("sv_bn_act_maxpool_fwd", ptr(y), ptr(st.scale), ptr(st.shift), ptr(mp), ptr(idx), I, 112, 112, 64, ACT_RELU, 0.0)
+        else:
+            z = empty(M, 64, like=x16)
+            st.apply(y, 64, z, 64, ACT_RELU, 0.0)
+            call("sv_maxpool2d_fwd", ptr(z), ptr(mp), ptr(idx), I, 112, 112, 64)
+        return mp, (1, 56, 56), (x16, y, st, M, I, idx, fused)
 
-    def _stem_bwd(self, ctx, dz, grads):
-        x16, y, st, M, I = ctx
+    def _stem_bwd(self, ctx, dmp, grads):
+        """dmp: gradient of the pooled 56 x 56 x 64 map"""
+        x16, y, st, M, I, idx, fused = ctx
         conv, bn = self.resnet[0], self.resnet[1]
-        dy = empty(M, 64, like=dz)
-        st.backward(dz, 64, None, 64, y, 64, dy, 64, grads[bn.weight], grads[bn.bias], ACT_RELU, 0.0)
+        dy = empty(M, 64, like=dmp)
+        if fused:
+            ws = ops.zeros_f64((ops.BN_BWD_SLOTS + 1) * 2 * 64 + 2, dmp.device)
+            call("sv_bn_maxpool_bwd", ptr(dmp), ptr(idx), ptr(y), ptr(bn.weight), ptr(st.mean), ptr(st.rstd), ptr(st.scale), ptr(st.shift), I, 112, 112, 64,
+                 ACT_RELU, 0.0, 1 if st.training else 0, ptr(dy), ptr(grads[bn.weight]), ptr(grads[bn.bias]), ptr(ws))
+        else:
+            dz = empty(M, 64, like=dmp)                                      # the gather-form max-pool backward writes every element
+            call("sv_maxpool2d_bwd", ptr(dmp), ptr(idx), ptr(dz), I, 112, 112, 64)
+            st.backward(dz, 64, None, 64, y, 64, dy, 64, grads[bn.weight], grads[bn.bias], ACT_RELU, 0.0)
         dw16 = ops.fzeros(64, 16, 4, 4, like=dy)                         # native layout of the 4x4 formulation: [co][(sy,sx,c)][ty][tx]
         self._stem_spec.wgrad(dy, x16, I, (1, 112, 112), dw16, async_ok=False)   # read back right below
         call("sv_stem_unpack_grad", ptr(dw16), ptr(grads[conv.weight]))  # dw[co][c][ky][kx] += dw16[co][(sy,sx,c)][ty][tx]
@@ -169,11 +187,7 @@ class Encoder(HipModule):
         with torch.cuda.stream(side):
             feats, swin_tape = swin_forward(self.swin_transformer, img, I, tr, sto, seeds, ready, save)
         # ---- ResNet trunk
-        x, g, c_stem = self._stem_fwd(images, I, tr)
-        mp = empty(I * 56 * 56, 64, like=x)
-        mp_idx = torch.empty(I * 56 * 56 * 64, dtype=torch.uint8, device=x.device)
-        call("sv_maxpool2d_fwd", ptr(x), ptr(mp), ptr(mp_idx), I, 112, 112, 64)
-        x, g = mp, (1, 56, 56)
+        x, g, c_stem = self._stem_fwd(images, I, tr)                       # stem conv + BatchNorm + ReLU + max-pool
         c_blocks = []
         for li in (4, 5, 6):
             for blk in self.resnet[li]:
@@ -200,7 +214,7 @@ class Encoder(HipModule):
             c_post.append(c)
         out = empty(B, V, 256, 7, 7, like=x)
         ops.transpose(y, out, I, 49, 256)                                  # [I][49][256] -> [I][256][49]
-        tape = (B, V, c_stem, mp_idx, c_blocks, res_feat, rr, swin_tape, neck, c_cva, c_post) if save else None
+        tape = (B, V, c_stem, c_blocks, res_feat, rr, swin_tape, neck, c_cva, c_post) if save else None
         return ops.to_f32(out), tape
 
     def _swin_neck_fwd(self, feats, ready, cat, I, tr, multi, stream):
@@ -235,7 +249,7 @@ class Encoder(HipModule):
         return neck
 
     def _bwd(self, tape, grads, in_needs, dout):
-        B, V, c_stem, mp_idx, c_blocks, res_feat, rr, swin_tape, neck, c_cva, c_post = tape
+        B, V, c_stem, c_blocks, res_feat, rr, swin_tape, neck, c_cva, c_post = tape
         I = B * V
         multi = self.cfg.NETWORK.USE_SWIN_T_MULTI_STAGE
         dout = ops.to_store(dout)
@@ -298,9 +312,7 @@ class Encoder(HipModule):
         self._s_rr.dgrad(drr, I * 196, (1, 1, 1), self._s_rr.pack_dgrad(self.resnet_reduce.weight), d)
         for blk, c in reversed(c_blocks):
             d = blk.bwd(c, d, grads)
-        dmp = empty(I * 112 * 112, 64, like=dout)                            # the gather-form max-pool backward writes every element
-        call("sv_maxpool2d_bwd", ptr(d), ptr(mp_idx), ptr(dmp), I, 112, 112, 64)
-        self._stem_bwd(c_stem, dmp, grads)
+        self._stem_bwd(c_stem, d, grads)                                   # max-pool + BatchNorm + stem conv
         self._announce(grads, 2)                                           # ResNet trunk
         main.wait_stream(side)                                             # join: every parameter gradient is complete
         if not tail_on_main:

@@ -581,10 +581,13 @@ class BatchNormState:
         call("sv_bn_finalize", ptr(self.sums), self.M, ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
              float(mom), float(bn.eps), 1 if self.training else 0, ptr(self.scale), ptr(self.shift), ptr(self.mean), ptr(self.rstd), self.C)
 
-    def apply(self, x, ldx, y, ldy, act=ACT_NONE, slope=0.0, residual=None, ldr=0):
+    def probe(self, x, ldx):
         probe = _STATE.get("bn_probe")
         if probe is not None:        # debug hook (tests): the producer's statistics next to the output it stored
             probe(self, x, ldx)
+
+    def apply(self, x, ldx, y, ldy, act=ACT_NONE, slope=0.0, residual=None, ldr=0):
+        self.probe(x, ldx)
         self.signs = None
         if (residual is not None and act != ACT_NONE and self.training and _bn_signs_on() and self.C % 256 == 0
                 and self.C % 4 == 0 and ldx % 4 == 0 and ldy % 4 == 0 and ldr % 4 == 0):
@@ -617,6 +620,17 @@ def _bn_signs_on() -> bool:
 def set_bn_signs(on: bool) -> None:
     """A/B switch: False keeps the stored output as the activation mask of the BatchNorms in front of a residual sum."""
     _STATE["bn_signs"] = bool(on)
+
+
+def stem_fused_enabled() -> bool:
+    import os
+    return _STATE.get("stem_fused", os.environ.get("SV_STEM_FUSED", "1") != "0")
+
+
+def set_stem_fused(on: bool) -> None:
+    """A/B switch of the ResNet stem: True (default) = BatchNorm + ReLU + max-pool in one pass and the pool's backward inside the BatchNorm
+    backward (sv_bn_act_maxpool_fwd / sv_bn_maxpool_bwd), False = the separate passes."""
+    _STATE["stem_fused"] = bool(on)
 
 
 def set_conv_halo(mode: int) -> None:

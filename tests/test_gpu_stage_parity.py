@@ -198,7 +198,6 @@ def test_resnet_layer_backward_bf16_vs_fp32_oracle(dev, step, li):
 def test_resnet_stem_backward_bf16_vs_fp32_oracle(dev, step):
     """7x7 / stride-2 stem (4x4 convolution on the space-to-depth image here) + BatchNorm + ReLU + 3x3 / stride-2 max-pool: output and the
     gradients of the stem weight and the BatchNorm parameters (the image needs no gradient)."""
-    from swinvox_amd.ops import call, empty, ptr
     enc, penc, units, rec = step
     x, dy = rec["stem"]["x"], rec["stem"]["dy"]                   # [I,3,224,224] / [I,64,56,56]
     ref = _oracle_unit(units["stem"], x, dy, autocast=False)
@@ -208,15 +207,10 @@ def test_resnet_stem_backward_bf16_vs_fp32_oracle(dev, step):
     _bf16()
     try:
         imgs = ops.to_store(x.to(dev))
-        z, g, c_stem = penc._stem_fwd(imgs, I, True)
-        mp = empty(I * 56 * 56, 64, like=z)
-        idx = torch.empty(I * 56 * 56 * 64, dtype=torch.uint8, device=dev)
-        call("sv_maxpool2d_fwd", ptr(z), ptr(mp), ptr(idx), I, 112, 112, 64)
+        mp, g, c_stem = penc._stem_fwd(imgs, I, True)                 # conv + BatchNorm + ReLU + max-pool (fused passes)
         y32 = _nchw(ops.to_f32(mp).cpu(), I, 56, 56)
         d = ops.to_store(_cl(dy).to(dev))
-        dmp = empty(I * 112 * 112, 64, like=d)
-        call("sv_maxpool2d_bwd", ptr(d), ptr(idx), ptr(dmp), I, 112, 112, 64)
-        penc._stem_bwd(c_stem, dmp, grads)
+        penc._stem_bwd(c_stem, d, grads)
         torch.cuda.synchronize()
     finally:
         ops.bn_tick_flush()
