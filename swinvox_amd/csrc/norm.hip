@@ -884,96 +884,109 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const AT* __rest
 //             the activation is ever stored.
 // A thread owns 4 adjacent channels; a workgroup walks whole image rows (no per-position divisions).
 // ------------------------------------------------------------------------------------------------
-template <typename AT>
+// CV = channels per thread: 8 with bf16 storage (16-byte accesses), else 4
+template <int CV> struct TapWord;
+template <> struct TapWord<4> { typedef unsigned type; };
+template <> struct TapWord<8> { typedef unsigned long long type; };
+template <int CV> __device__ __forceinline__ void ld_taps(const uint8_t* p, int (&t)[CV]) {
+  const typename TapWord<CV>::type w = *reinterpret_cast<const typename TapWord<CV>::type*>(p);
+#pragma unroll
+  for (int j = 0; j < CV; ++j) t[j] = (int)((w >> (8 * j)) & 0xff);
+}
+template <typename AT, int CV>
 __global__ __launch_bounds__(256) void bn_act_maxpool_fwd_kernel(const AT* __restrict__ x, const float* __restrict__ fsc, const float* __restrict__ fsh,
                                                                  AT* __restrict__ y, uint8_t* __restrict__ idx, int N, int H, int W, int C, int Ho, int Wo,
                                                                  int act, float slope) {
-  const int cv = C >> 2;
+  const int cv = C / CV;
   const long long total = (long long)N * Ho * Wo * cv;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % cv) * 4; long long t = i / cv;
+    const int c = (int)(i % cv) * CV; long long t = i / cv;
     const int ow = (int)(t % Wo); t /= Wo; const int oh = (int)(t % Ho); const int n = (int)(t / Ho);
-    const float4 sc = *reinterpret_cast<const float4*>(fsc + c), sh = *reinterpret_cast<const float4*>(fsh + c);
-    const float s_[4] = {sc.x, sc.y, sc.z, sc.w}, h_[4] = {sh.x, sh.y, sh.z, sh.w};
-    float best[4] = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
-    int bi[4] = {0, 0, 0, 0};
+    float s_[CV], h_[CV], best[CV];
+    int bi[CV];
+#pragma unroll
+    for (int j = 0; j < CV; ++j) { s_[j] = fsc[c + j]; h_[j] = fsh[c + j]; best[j] = -3.4e38f; bi[j] = 0; }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
         if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-          const float4 q = ld4f(x + (((size_t)n * H + ih) * W + iw) * C + c);
-          const float v[4] = {q.x, q.y, q.z, q.w};
+          float v[CV];
+          ldnf<CV>(x + (((size_t)n * H + ih) * W + iw) * C + c, v);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < CV; ++j) {
             const float z = (float)(AT)apply_act(__fmaf_rn(v[j], s_[j], h_[j]), act, slope);   // what scale_shift_act would have stored
             if (z > best[j]) { best[j] = z; bi[j] = kh * 3 + kw; }
           }
         }
       }
     const size_t o = (((size_t)n * Ho + oh) * Wo + ow) * C + c;
-    st4f(y + o, make_float4(best[0], best[1], best[2], best[3]));
-    *reinterpret_cast<uchar4*>(idx + o) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+    stnf<CV>(y + o, best);
+    typename TapWord<CV>::type w = 0;
+#pragma unroll
+    for (int j = 0; j < CV; ++j) w |= (typename TapWord<CV>::type)bi[j] << (8 * j);
+    *reinterpret_cast<typename TapWord<CV>::type*>(idx + o) = w;
   }
 }
 
-// The pool's data gradient for the 2 x 2 input block (2a .. 2a + 1, 2b .. 2b + 1), channels c .. c + 3: the block lies in the windows (a, b),
+// The pool's data gradient for the 2 x 2 input block (2a .. 2a + 1, 2b .. 2b + 1), channels c .. c + CV - 1: the block lies in the windows (a, b),
 // (a, b + 1), (a + 1, b), (a + 1, b + 1) only, so four pooled gradients + their arg-max taps (tap = 3 kh + kw, input = 2 o - 1 + k) serve four
 // positions - and all four loads go out together (the per-position gather form of maxpool2d_bwd_kernel re-reads each pooled element 2.25
 // times behind data-dependent loop bounds: 1.57 ms for the two passes against 1.51 for the separate kernels).  d[p][j]: p = 2 * dy + dx.
-template <typename AT>
+template <typename AT, int CV>
 __device__ __forceinline__ void pool_block_grad(const AT* __restrict__ dmp, const uint8_t* __restrict__ idx, int n, int a, int b, int c, int C, int Ho, int Wo,
-                                                float d[4][4]) {
+                                                float (&d)[4][CV]) {
   const size_t o00 = (((size_t)n * Ho + a) * Wo + b) * C + c;
   const bool vb = b + 1 < Wo, va = a + 1 < Ho;
   const size_t o01 = vb ? o00 + C : o00, o10 = va ? o00 + (size_t)Wo * C : o00, o11 = (va && vb) ? o00 + (size_t)Wo * C + C : o00;
-  const float4 g00 = ld4f(dmp + o00), g01 = ld4f(dmp + o01), g10 = ld4f(dmp + o10), g11 = ld4f(dmp + o11);
-  const uchar4 i00 = *reinterpret_cast<const uchar4*>(idx + o00), i01 = *reinterpret_cast<const uchar4*>(idx + o01);
-  const uchar4 i10 = *reinterpret_cast<const uchar4*>(idx + o10), i11 = *reinterpret_cast<const uchar4*>(idx + o11);
-  const float G[4][4] = {{g00.x, g00.y, g00.z, g00.w}, {g01.x, g01.y, g01.z, g01.w}, {g10.x, g10.y, g10.z, g10.w}, {g11.x, g11.y, g11.z, g11.w}};
-  const int I0[4] = {i00.x, i00.y, i00.z, i00.w};
-  const int I1[4] = {vb ? i01.x : 255, vb ? i01.y : 255, vb ? i01.z : 255, vb ? i01.w : 255};
-  const int I2[4] = {va ? i10.x : 255, va ? i10.y : 255, va ? i10.z : 255, va ? i10.w : 255};
-  const int I3[4] = {(va && vb) ? i11.x : 255, (va && vb) ? i11.y : 255, (va && vb) ? i11.z : 255, (va && vb) ? i11.w : 255};
+  float g0[CV], g1[CV], g2[CV], g3[CV];
+  int i0[CV], i1[CV], i2[CV], i3[CV];
+  ldnf<CV>(dmp + o00, g0); ldnf<CV>(dmp + o01, g1); ldnf<CV>(dmp + o10, g2); ldnf<CV>(dmp + o11, g3);
+  ld_taps<CV>(idx + o00, i0); ld_taps<CV>(idx + o01, i1); ld_taps<CV>(idx + o10, i2); ld_taps<CV>(idx + o11, i3);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    d[0][j] = I0[j] == 4 ? G[0][j] : 0.f;
-    d[1][j] = (I0[j] == 5 ? G[0][j] : 0.f) + (I1[j] == 3 ? G[1][j] : 0.f);
-    d[2][j] = (I0[j] == 7 ? G[0][j] : 0.f) + (I2[j] == 1 ? G[2][j] : 0.f);
-    d[3][j] = (I0[j] == 8 ? G[0][j] : 0.f) + (I1[j] == 6 ? G[1][j] : 0.f) + (I2[j] == 2 ? G[2][j] : 0.f) + (I3[j] == 0 ? G[3][j] : 0.f);
+  for (int j = 0; j < CV; ++j) {
+    const int t1 = vb ? i1[j] : 255, t2 = va ? i2[j] : 255, t3 = (va && vb) ? i3[j] : 255;
+    d[0][j] = i0[j] == 4 ? g0[j] : 0.f;
+    d[1][j] = (i0[j] == 5 ? g0[j] : 0.f) + (t1 == 3 ? g1[j] : 0.f);
+    d[2][j] = (i0[j] == 7 ? g0[j] : 0.f) + (t2 == 1 ? g2[j] : 0.f);
+    d[3][j] = (i0[j] == 8 ? g0[j] : 0.f) + (t1 == 6 ? g1[j] : 0.f) + (t2 == 2 ? g2[j] : 0.f) + (t3 == 0 ? g3[j] : 0.f);
   }
 }
 
-// pass 1: G = C / 4 column groups x 256 / G block lanes; blockIdx.x owns image-row PAIRS [blockIdx.x * rpb, +rpb) of the N * Ho pairs
-template <typename AT>
+// pass 1: G = C / CV column groups x 256 / G block lanes; blockIdx.x owns image-row PAIRS [blockIdx.x * rpb, +rpb) of the N * Ho pairs
+template <typename AT, int CV>
 __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const AT* __restrict__ dmp, const uint8_t* __restrict__ idx, const AT* __restrict__ x,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ fsc, const float* __restrict__ fsh, double* __restrict__ sums,
                                                                  int N, int H, int W, int C, int Ho, int Wo, int act, float slope, int rpb) {
-  __shared__ double red[256][9];
-  const int G = C >> 2, gq = threadIdx.x % G, rl = threadIdx.x / G, RL = 256 / G, c = gq * 4;
-  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  __shared__ double red[256][2 * CV + 1];
+  const int G = C / CV, gq = threadIdx.x % G, rl = threadIdx.x / G, RL = 256 / G, c = gq * CV;
+  double s1[CV], s2[CV];
+#pragma unroll
+  for (int j = 0; j < CV; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
   if (rl < RL) {
-    const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
-    const float4 sc = *reinterpret_cast<const float4*>(fsc + c), sh = *reinterpret_cast<const float4*>(fsh + c);
-    const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w}, s_[4] = {sc.x, sc.y, sc.z, sc.w}, h_[4] = {sh.x, sh.y, sh.z, sh.w};
+    float mm[CV], rr[CV], s_[CV], h_[CV];
+#pragma unroll
+    for (int j = 0; j < CV; ++j) { mm[j] = mean[c + j]; rr[j] = rstd[c + j]; s_[j] = fsc[c + j]; h_[j] = fsh[c + j]; }
     const float neg = act == SV_ACT_LRELU ? slope : 0.f;
     const int rp0 = blockIdx.x * rpb, rp1 = min(rp0 + rpb, N * Ho);
     for (int rp = rp0; rp < rp1; ++rp) {
       const int n = rp / Ho, a = rp - n * Ho;
-      float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};      // one row pair per lane in fp32 (<= 4 Wo / RL terms), then double
+      float t1[CV], t2[CV];      // one row pair per lane in fp32 (<= 4 Wo / RL terms), then double
+#pragma unroll
+      for (int j = 0; j < CV; ++j) { t1[j] = 0.f; t2[j] = 0.f; }
       for (int b = rl; b < Wo; b += RL) {
-        float d[4][4];
-        pool_block_grad(dmp, idx, n, a, b, c, C, Ho, Wo, d);
+        float d[4][CV];
+        pool_block_grad<AT, CV>(dmp, idx, n, a, b, c, C, Ho, Wo, d);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const int ih = 2 * a + (p >> 1), iw = 2 * b + (p & 1);
           if (ih < H && iw < W) {
-            const float4 xv = ld4f(x + (((size_t)n * H + ih) * W + iw) * C + c);
-            const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+            float xx[CV];
+            ldnf<CV>(x + (((size_t)n * H + ih) * W + iw) * C + c, xx);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < CV; ++j) {
               float dd = d[p][j];
               if (act != SV_ACT_NONE) dd *= __fmaf_rn(xx[j], s_[j], h_[j]) > 0.f ? 1.f : neg;
               t1[j] += dd; t2[j] += dd * (xx[j] - mm[j]) * rr[j];
@@ -982,35 +995,35 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const AT* __res
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { s1[j] += (double)t1[j]; s2[j] += (double)t2[j]; }
+      for (int j = 0; j < CV; ++j) { s1[j] += (double)t1[j]; s2[j] += (double)t2[j]; }
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][4 + j] = s2[j]; }
+  for (int j = 0; j < CV; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][CV + j] = s2[j]; }
   __syncthreads();
-  for (int t = threadIdx.x; t < 8 * G; t += 256) {
-    const int q = t >> 3, k = t & 7;
+  for (int t = threadIdx.x; t < 2 * CV * G; t += 256) {
+    const int q = t / (2 * CV), k = t % (2 * CV);
     double acc = 0.0;
     for (int l = 0; l < RL; ++l) acc += red[l * G + q][k];
-    atomicAdd(sums + (size_t)(blockIdx.x % BN_BWD_SLOTS) * 2 * C + (k < 4 ? 0 : C) + q * 4 + (k & 3), acc);
+    atomicAdd(sums + (size_t)(blockIdx.x % BN_BWD_SLOTS) * 2 * C + (k < CV ? 0 : C) + q * CV + (k % CV), acc);
   }
 }
 
 // pass 2: dx = k1 dz' - k2 - k3 x (double coefficients: the mean-removal terms must cancel to rounding), dz' gathered again
-template <typename AT>
+template <typename AT, int CV>
 __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const AT* __restrict__ dmp, const uint8_t* __restrict__ idx, const AT* __restrict__ x,
                                                                 const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ fsc, const float* __restrict__ fsh, const double* __restrict__ sums,
                                                                 AT* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo, int act, float slope,
                                                                 int training, int rpb) {
-  const int G = C >> 2, gq = threadIdx.x % G, rl = threadIdx.x / G, RL = 256 / G, c = gq * 4;
+  const int G = C / CV, gq = threadIdx.x % G, rl = threadIdx.x / G, RL = 256 / G, c = gq * CV;
   if (rl >= RL) return;
   sums += (size_t)BN_BWD_SLOTS * 2 * C;     // the folded image (bn_bwd_fold_kernel)
-  double k1[4], k2[4], k3[4];
-  float s_[4], h_[4];
+  double k1[CV], k2[CV], k3[CV];
+  float s_[CV], h_[CV];
   const double invM = 1.0 / ((double)N * H * W);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < CV; ++j) {
     const double gm = gamma[c + j], rs = rstd[c + j], mu = mean[c + j];
     k1[j] = gm * rs;
     if (training) { const double sa = sums[c + j] * invM, sb = sums[C + c + j] * invM; k3[j] = gm * rs * sb * rs; k2[j] = gm * rs * sa - k3[j] * mu; }
@@ -1022,23 +1035,22 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const AT* __rest
   for (int rp = rp0; rp < rp1; ++rp) {
     const int n = rp / Ho, a = rp - n * Ho;
     for (int b = rl; b < Wo; b += RL) {
-      float d[4][4];
-      pool_block_grad(dmp, idx, n, a, b, c, C, Ho, Wo, d);
+      float d[4][CV];
+      pool_block_grad<AT, CV>(dmp, idx, n, a, b, c, C, Ho, Wo, d);
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int ih = 2 * a + (p >> 1), iw = 2 * b + (p & 1);
         if (ih < H && iw < W) {
           const size_t o = (((size_t)n * H + ih) * W + iw) * C + c;
-          const float4 xv = ld4f(x + o);
-          const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
-          float out[4];
+          float xx[CV], out[CV];
+          ldnf<CV>(x + o, xx);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < CV; ++j) {
             float dd = d[p][j];
             if (act != SV_ACT_NONE) dd *= __fmaf_rn(xx[j], s_[j], h_[j]) > 0.f ? 1.f : neg;
             out[j] = (float)(k1[j] * (double)dd - k2[j] - k3[j] * (double)xx[j]);
           }
-          st4f(dx + o, make_float4(out[0], out[1], out[2], out[3]));
+          stnf<CV>(dx + o, out);
         }
       }
     }
@@ -1238,6 +1250,10 @@ extern "C" int sv_scale_shift_act_signs(const void* x, int ldx, const float* sca
 static bool bn_pool_shape_ok(int N, int H, int W, int C) {
   return N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && (long long)N * H * W * C < (1ll << 40);
 }
+// 8 channels per thread (16-byte accesses): bf16 storage, C % 8 == 0 with 256 % (C / 8) == 0, 16-byte aligned tensors, 8-byte aligned tap words
+static bool bn_pool_cv8(int act_dtype, int C, const void* a, const void* b, const void* c) {
+  return act_dtype == SV_BF16 && C % 8 == 0 && 256 % (C / 8) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0;
+}
 extern "C" int sv_bn_act_maxpool_fwd(const void* x, const float* scale, const float* shift, void* pooled, void* idx, int N, int H, int W, int C,
                                      int act, float slope, int act_dtype, void* stream) {
   SV_REQUIRE(x && scale && shift && pooled && idx && bn_pool_shape_ok(N, H, W, C), "bn_act_maxpool_fwd: bad arguments (N=%d H=%d W=%d C=%d)", N, H, W, C);
@@ -1247,7 +1263,14 @@ extern "C" int sv_bn_act_maxpool_fwd(const void* x, const float* scale, const fl
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const long long total = (long long)N * Ho * Wo * (C / 4);
   long long blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384;
-  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(bn_act_maxpool_fwd_kernel<AT>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const AT*>(x),
+  if (bn_pool_cv8(act_dtype, C, x, pooled, idx)) {
+    const long long t8 = total / 2;
+    long long b8 = (t8 + 255) / 256; if (b8 > 16384) b8 = 16384;
+    hipLaunchKernelGGL((bn_act_maxpool_fwd_kernel<__bf16, 8>), dim3((unsigned)b8), dim3(256), 0, (hipStream_t)stream, static_cast<const __bf16*>(x),
+                       scale, shift, static_cast<__bf16*>(pooled), static_cast<uint8_t*>(idx), N, H, W, C, Ho, Wo, act, slope);
+    return check_launch("sv_bn_act_maxpool_fwd");
+  }
+  SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL((bn_act_maxpool_fwd_kernel<AT, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const AT*>(x),
                                                 scale, shift, static_cast<AT*>(pooled), static_cast<uint8_t*>(idx), N, H, W, C, Ho, Wo, act, slope););
   return check_launch("sv_bn_act_maxpool_fwd");
 }
@@ -1268,11 +1291,20 @@ extern "C" int sv_bn_maxpool_bwd(const void* dpooled, const void* idx, const voi
   const unsigned nb = (unsigned)((rows + rpb - 1) / rpb);
   int rpa = (int)((rows + 8191) / 8192); if (rpa < 1) rpa = 1;
   const unsigned na = (unsigned)((rows + rpa - 1) / rpa);
-  SV_DISPATCH_ACT(act_dtype,
-    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel<AT>, dim3(nb), dim3(256), 0, s, static_cast<const AT*>(dpooled), static_cast<const uint8_t*>(idx), static_cast<const AT*>(x),
+  if (bn_pool_cv8(act_dtype, C, dpooled, x, dx) && ((uintptr_t)idx & 7) == 0) {
+    typedef __bf16 AT;
+    hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<AT, 8>), dim3(nb), dim3(256), 0, s, static_cast<const AT*>(dpooled), static_cast<const uint8_t*>(idx), static_cast<const AT*>(x),
                        save_mean, save_rstd, fwd_scale, fwd_shift, sums_ws, N, H, W, C, Ho, Wo, act, slope, rpb);
     hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);
-    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel<AT>, dim3(na), dim3(256), 0, s, static_cast<const AT*>(dpooled), static_cast<const uint8_t*>(idx), static_cast<const AT*>(x),
+    hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<AT, 8>), dim3(na), dim3(256), 0, s, static_cast<const AT*>(dpooled), static_cast<const uint8_t*>(idx), static_cast<const AT*>(x),
+                       gamma, save_mean, save_rstd, fwd_scale, fwd_shift, sums_ws, static_cast<AT*>(dx), N, H, W, C, Ho, Wo, act, slope, training, rpa);
+    return check_launch("sv_bn_maxpool_bwd");
+  }
+  SV_DISPATCH_ACT(act_dtype,
+    hipLaunchKernelGGL((bn_pool_bwd_reduce_kernel<AT, 4>), dim3(nb), dim3(256), 0, s, static_cast<const AT*>(dpooled), static_cast<const uint8_t*>(idx), static_cast<const AT*>(x),
+                       save_mean, save_rstd, fwd_scale, fwd_shift, sums_ws, N, H, W, C, Ho, Wo, act, slope, rpb);
+    hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);
+    hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<AT, 4>), dim3(na), dim3(256), 0, s, static_cast<const AT*>(dpooled), static_cast<const uint8_t*>(idx), static_cast<const AT*>(x),
                        gamma, save_mean, save_rstd, fwd_scale, fwd_shift, sums_ws, static_cast<AT*>(dx), N, H, W, C, Ho, Wo, act, slope, training, rpa););
   return check_launch("sv_bn_maxpool_bwd");
 }
