@@ -201,6 +201,14 @@ int sv_bn_act_maxpool_fwd(const void* x, const float* scale, const float* shift,
 int sv_bn_maxpool_bwd(const void* dpooled, const void* idx, const void* x, const float* gamma, const float* save_mean, const float* save_rstd,
                       const float* fwd_scale, const float* fwd_shift, int N, int H, int W, int C, int act, float slope, int training,
                       void* dx, float* dgamma, float* dbeta, double* sums_ws, int act_dtype, void* stream);
+/* The same fusion around MaxPool3d(2) (floor) for the Refiner's down-sampling layers (reference models/refiner.py:21-39): x [N, D, H, W, C] ->
+ * pooled / idx [N, D/2, H/2, W/2, C] (tap = 4 dz + 2 dy + dx, as sv_maxpool3d_fwd); the backward writes dx for every input position, the planes of an
+ * odd grid that no window covers included. */
+int sv_bn_act_maxpool3d_fwd(const void* x, const float* scale, const float* shift, void* pooled, void* idx, int N, int D, int H, int W, int C,
+                            int act, float slope, int act_dtype, void* stream);
+int sv_bn_maxpool3d_bwd(const void* dpooled, const void* idx, const void* x, const float* gamma, const float* save_mean, const float* save_rstd,
+                        const float* fwd_scale, const float* fwd_shift, int N, int D, int H, int W, int C, int act, float slope, int training,
+                        void* dx, float* dgamma, float* dbeta, double* sums_ws, int act_dtype, void* stream);
 size_t sv_bn_bwd_workspace_doubles(int C);   /* size of sums_ws below */
 int sv_bn_bwd(const void* dz, int lddz, const void* z, int ldz, const void* x, int ldx, const float* gamma,
               const float* save_mean, const float* save_rstd, long long M, int C, int act, float slope, int training,

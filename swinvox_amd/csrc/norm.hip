@@ -1057,6 +1057,126 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const AT* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same fusion around MaxPool3d(2) (floor: 33 -> 16, 17 -> 8, 9 -> 4) for the three down-sampling layers of the Refiner (reference
+// models/refiner.py:21-39: Conv3d -> BatchNorm3d -> LeakyReLU -> MaxPool3d): windows do not overlap, an input position lies in at most one
+// window and the last plane of an odd grid in none.  tap = 4 dz + 2 dy + dx (sv_maxpool3d_fwd's numbering).  A thread owns CV channels of one
+// window (forward) / of one 2 x 2 x 2 input block, partial blocks at the far faces included (backward: their gradient is -k2 - k3 x).
+// ------------------------------------------------------------------------------------------------
+template <typename AT, int CV>
+__global__ __launch_bounds__(256) void bn_act_maxpool3d_fwd_kernel(const AT* __restrict__ x, const float* __restrict__ fsc, const float* __restrict__ fsh,
+                                                                   AT* __restrict__ y, uint8_t* __restrict__ idx, int N, int D, int H, int W, int C,
+                                                                   int act, float slope) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2, cv = C / CV;
+  const long long total = (long long)N * Do * Ho * Wo * cv;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cv) * CV; long long t = i / cv;
+    const int ow = (int)(t % Wo); t /= Wo; const int oh = (int)(t % Ho); t /= Ho; const int od = (int)(t % Do); const int n = (int)(t / Do);
+    float s_[CV], h_[CV], best[CV];
+    int bi[CV];
+#pragma unroll
+    for (int j = 0; j < CV; ++j) { s_[j] = fsc[c + j]; h_[j] = fsh[c + j]; best[j] = -3.4e38f; bi[j] = 0; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float v[CV];
+      ldnf<CV>(x + ((((size_t)n * D + od * 2 + (k >> 2)) * H + oh * 2 + ((k >> 1) & 1)) * W + ow * 2 + (k & 1)) * C + c, v);
+#pragma unroll
+      for (int j = 0; j < CV; ++j) {
+        const float z = (float)(AT)apply_act(__fmaf_rn(v[j], s_[j], h_[j]), act, slope);   // what scale_shift_act would have stored
+        if (z > best[j]) { best[j] = z; bi[j] = k; }
+      }
+    }
+    const size_t o = ((((size_t)n * Do + od) * Ho + oh) * Wo + ow) * C + c;
+    stnf<CV>(y + o, best);
+    typename TapWord<CV>::type w = 0;
+#pragma unroll
+    for (int j = 0; j < CV; ++j) w |= (typename TapWord<CV>::type)bi[j] << (8 * j);
+    *reinterpret_cast<typename TapWord<CV>::type*>(idx + o) = w;
+  }
+}
+
+// APPLY = false: pass 1 (sums of dz' and dz' * xhat into slot images); APPLY = true: pass 2 (dx = k1 dz' - k2 - k3 x)
+template <typename AT, int CV, bool APPLY>
+__global__ __launch_bounds__(256) void bn_pool3d_bwd_kernel(const AT* __restrict__ dmp, const uint8_t* __restrict__ idx, const AT* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ fsc, const float* __restrict__ fsh, double* __restrict__ sums,
+                                                            AT* __restrict__ dx, int N, int D, int H, int W, int C, int act, float slope, int training,
+                                                            long long bpw) {
+  __shared__ double red[APPLY ? 1 : 256][2 * CV + 1];
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2, BD = (D + 1) / 2, BH = (H + 1) / 2, BW = (W + 1) / 2;
+  const int G = C / CV, gq = threadIdx.x % G, rl = threadIdx.x / G, RL = 256 / G, c = gq * CV;
+  const long long nblk = (long long)N * BD * BH * BW;
+  const long long q0 = (long long)blockIdx.x * bpw, q1 = q0 + bpw < nblk ? q0 + bpw : nblk;
+  double s1[CV], s2[CV], k1[CV], k2[CV], k3[CV];
+  float mm[CV], rr[CV], s_[CV], h_[CV];
+#pragma unroll
+  for (int j = 0; j < CV; ++j) { s1[j] = 0.0; s2[j] = 0.0; k1[j] = k2[j] = k3[j] = 0.0; mm[j] = rr[j] = s_[j] = h_[j] = 0.f; }
+  if (rl < RL) {
+#pragma unroll
+    for (int j = 0; j < CV; ++j) { mm[j] = mean[c + j]; rr[j] = rstd[c + j]; s_[j] = fsc[c + j]; h_[j] = fsh[c + j]; }
+    if constexpr (APPLY) {
+      const double* fin = sums + (size_t)BN_BWD_SLOTS * 2 * C;     // the folded image (bn_bwd_fold_kernel)
+      const double invM = 1.0 / ((double)N * D * H * W);
+#pragma unroll
+      for (int j = 0; j < CV; ++j) {
+        const double gm = gamma[c + j], rs = rr[j], mu = mm[j];
+        k1[j] = gm * rs;
+        if (training) { const double sa = fin[c + j] * invM, sb = fin[C + c + j] * invM; k3[j] = gm * rs * sb * rs; k2[j] = gm * rs * sa - k3[j] * mu; }
+      }
+    }
+    const float neg = act == SV_ACT_LRELU ? slope : 0.f;
+    for (long long q = q0 + rl; q < q1; q += RL) {
+      long long t = q;
+      const int bw = (int)(t % BW); t /= BW; const int bh = (int)(t % BH); t /= BH; const int bd = (int)(t % BD); const int n = (int)(t / BD);
+      const bool win = bd < Do && bh < Ho && bw < Wo;
+      float g[CV];
+      int tp[CV];
+#pragma unroll
+      for (int j = 0; j < CV; ++j) { g[j] = 0.f; tp[j] = 255; }
+      if (win) {
+        const size_t o = ((((size_t)n * Do + bd) * Ho + bh) * Wo + bw) * C + c;
+        ldnf<CV>(dmp + o, g);
+        ld_taps<CV>(idx + o, tp);
+      }
+      float t1[CV], t2[CV];
+#pragma unroll
+      for (int j = 0; j < CV; ++j) { t1[j] = 0.f; t2[j] = 0.f; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int id = 2 * bd + (k >> 2), ih = 2 * bh + ((k >> 1) & 1), iw = 2 * bw + (k & 1);
+        if (id < D && ih < H && iw < W) {
+          const size_t o = ((((size_t)n * D + id) * H + ih) * W + iw) * C + c;
+          float xx[CV], out[CV];
+          ldnf<CV>(x + o, xx);
+#pragma unroll
+          for (int j = 0; j < CV; ++j) {
+            float dd = tp[j] == k ? g[j] : 0.f;
+            if (act != SV_ACT_NONE) dd *= __fmaf_rn(xx[j], s_[j], h_[j]) > 0.f ? 1.f : neg;
+            if constexpr (APPLY) out[j] = (float)(k1[j] * (double)dd - k2[j] - k3[j] * (double)xx[j]);
+            else { t1[j] += dd; t2[j] += dd * (xx[j] - mm[j]) * rr[j]; }
+          }
+          if constexpr (APPLY) stnf<CV>(dx + o, out);
+        }
+      }
+      if constexpr (!APPLY) {
+#pragma unroll
+        for (int j = 0; j < CV; ++j) { s1[j] += (double)t1[j]; s2[j] += (double)t2[j]; }
+      }
+    }
+  }
+  if constexpr (!APPLY) {
+#pragma unroll
+    for (int j = 0; j < CV; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][CV + j] = s2[j]; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * CV * G; t += 256) {
+      const int q = t / (2 * CV), k = t % (2 * CV);
+      double acc = 0.0;
+      for (int l = 0; l < RL; ++l) acc += red[l * G + q][k];
+      atomicAdd(sums + (size_t)(blockIdx.x % BN_BWD_SLOTS) * 2 * C + (k < CV ? 0 : C) + q * CV + (k % CV), acc);
+    }
+  }
+}
+
 }  // namespace sv
 
 using namespace sv;
@@ -1307,6 +1427,53 @@ extern "C" int sv_bn_maxpool_bwd(const void* dpooled, const void* idx, const voi
     hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<AT, 4>), dim3(na), dim3(256), 0, s, static_cast<const AT*>(dpooled), static_cast<const uint8_t*>(idx), static_cast<const AT*>(x),
                        gamma, save_mean, save_rstd, fwd_scale, fwd_shift, sums_ws, static_cast<AT*>(dx), N, H, W, C, Ho, Wo, act, slope, training, rpa););
   return check_launch("sv_bn_maxpool_bwd");
+}
+
+/* Refiner down-sampling layers: BatchNorm3d + activation + MaxPool3d(2) in one pass over the convolution's output x [N, D, H, W, C] (rows of exactly C
+ * elements; C % 4 == 0 and 256 % (C / 4) == 0), pooled / idx [N, D/2, H/2, W/2, C] */
+extern "C" int sv_bn_act_maxpool3d_fwd(const void* x, const float* scale, const float* shift, void* pooled, void* idx, int N, int D, int H, int W, int C,
+                                       int act, float slope, int act_dtype, void* stream) {
+  SV_REQUIRE(x && scale && shift && pooled && idx && D > 1 && bn_pool_shape_ok(N, H, W, C) && (long long)N * D * H * W * C < (1ll << 40),
+             "bn_act_maxpool3d_fwd: bad arguments (N=%d D=%d H=%d W=%d C=%d)", N, D, H, W, C);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_REQUIRE(aligned4(act_dtype, x, pooled, nullptr, nullptr, nullptr) && ((uintptr_t)idx & 3) == 0, "bn_act_maxpool3d_fwd: misaligned buffers");
+  const long long win = (long long)N * (D / 2) * (H / 2) * (W / 2);
+  if (win == 0) return SV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (bn_pool_cv8(act_dtype, C, x, pooled, idx)) {
+    long long blocks = (win * (C / 8) + 255) / 256; if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((bn_act_maxpool3d_fwd_kernel<__bf16, 8>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const __bf16*>(x), scale, shift,
+                       static_cast<__bf16*>(pooled), static_cast<uint8_t*>(idx), N, D, H, W, C, act, slope);
+  } else {
+    long long blocks = (win * (C / 4) + 255) / 256; if (blocks > 16384) blocks = 16384;
+    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL((bn_act_maxpool3d_fwd_kernel<AT, 4>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const AT*>(x), scale, shift,
+                                                  static_cast<AT*>(pooled), static_cast<uint8_t*>(idx), N, D, H, W, C, act, slope););
+  }
+  return check_launch("sv_bn_act_maxpool3d_fwd");
+}
+extern "C" int sv_bn_maxpool3d_bwd(const void* dpooled, const void* idx, const void* x, const float* gamma, const float* save_mean, const float* save_rstd,
+                                   const float* fwd_scale, const float* fwd_shift, int N, int D, int H, int W, int C, int act, float slope, int training,
+                                   void* dx, float* dgamma, float* dbeta, double* sums_ws, int act_dtype, void* stream) {
+  SV_REQUIRE(dpooled && idx && x && gamma && save_mean && save_rstd && fwd_scale && fwd_shift && dx && dgamma && dbeta && sums_ws && D > 1 &&
+             bn_pool_shape_ok(N, H, W, C) && (long long)N * D * H * W * C < (1ll << 40), "bn_maxpool3d_bwd: bad arguments (N=%d D=%d H=%d W=%d C=%d)", N, D, H, W, C);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_REQUIRE(aligned4(act_dtype, dpooled, x, dx, nullptr, nullptr) && ((uintptr_t)idx & 3) == 0, "bn_maxpool3d_bwd: misaligned buffers");
+  hipStream_t s = (hipStream_t)stream;
+  const long long nblk = (long long)N * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
+  long long bpr = (nblk + 2047) / 2048, bpa = (nblk + 8191) / 8192;
+  const unsigned nr = (unsigned)((nblk + bpr - 1) / bpr), na = (unsigned)((nblk + bpa - 1) / bpa);
+#define SV_POOL3D_BWD(AT_, CV_)                                                                                                                             \
+  hipLaunchKernelGGL((bn_pool3d_bwd_kernel<AT_, CV_, false>), dim3(nr), dim3(256), 0, s, static_cast<const AT_*>(dpooled), static_cast<const uint8_t*>(idx),   \
+                     static_cast<const AT_*>(x), gamma, save_mean, save_rstd, fwd_scale, fwd_shift, sums_ws, static_cast<AT_*>(dx), N, D, H, W, C, act, slope,  \
+                     training, bpr);                                                                                                                        \
+  hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, sums_ws, C, dgamma, dbeta);                                               \
+  hipLaunchKernelGGL((bn_pool3d_bwd_kernel<AT_, CV_, true>), dim3(na), dim3(256), 0, s, static_cast<const AT_*>(dpooled), static_cast<const uint8_t*>(idx),    \
+                     static_cast<const AT_*>(x), gamma, save_mean, save_rstd, fwd_scale, fwd_shift, sums_ws, static_cast<AT_*>(dx), N, D, H, W, C, act, slope,  \
+                     training, bpa);
+  if (bn_pool_cv8(act_dtype, C, dpooled, x, dx) && ((uintptr_t)idx & 7) == 0) { SV_POOL3D_BWD(__bf16, 8) }
+  else { SV_DISPATCH_ACT(act_dtype, SV_POOL3D_BWD(AT, 4)); }
+#undef SV_POOL3D_BWD
+  return check_launch("sv_bn_maxpool3d_bwd");
 }
 
 extern "C" size_t sv_bn_bwd_workspace_doubles(int C) { return (size_t)(BN_BWD_SLOTS + 1) * 2 * C + 2; }

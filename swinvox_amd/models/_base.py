@@ -200,6 +200,40 @@ class ConvBnAct:
         sp.dgrad(dy, n, in_grid, self._pack("d"), dx, lddy=sp.cout_mem, lddx=lddx, **(dx_epi or {}))
         return dx
 
+    # ---- the layer followed by MaxPool3d(2): BatchNorm + activation + pool in one pass, the pool's backward inside the BatchNorm backward
+    def forward_pool3d(self, x, n, in_grid, training):
+        """-> (pooled [n * prod(og // 2), cout], og, ctx); the normalised activation is never stored (sv_bn_act_maxpool3d_fwd)"""
+        sp = self.spec
+        og = sp.out_grid(in_grid)
+        M = n * og[0] * og[1] * og[2]
+        y = empty(M, sp.cout, like=x)
+        st = BatchNormState(self.bn, M, training)
+        sp.forward(x, n, in_grid, self._pack("f"), y, bias=self.conv.bias, stats=st.sums)
+        st.finalize()
+        st.probe(y, sp.cout)
+        pg = (og[0] // 2, og[1] // 2, og[2] // 2)
+        p = empty(n * pg[0] * pg[1] * pg[2], sp.cout, like=x)
+        idx = torch.empty(p.numel(), dtype=torch.uint8, device=x.device)
+        call("sv_bn_act_maxpool3d_fwd", ptr(y), ptr(st.scale), ptr(st.shift), ptr(p), ptr(idx), n, og[0], og[1], og[2], sp.cout, self.act, self.slope)
+        return p, og, (x, y, st, n, in_grid, og, M, idx)
+
+    def backward_pool3d(self, ctx, dp, grads, *, need_dx=True):
+        x, y, st, n, in_grid, og, M, idx = ctx
+        sp = self.spec
+        assert sp.cout_mem == sp.cout
+        dy = empty(M, sp.cout, like=dp)
+        ws = ops.zeros_f64((ops.BN_BWD_SLOTS + 1) * 2 * sp.cout + 2, dp.device)
+        call("sv_bn_maxpool3d_bwd", ptr(dp), ptr(idx), ptr(y), ptr(self.bn.weight), ptr(st.mean), ptr(st.rstd), ptr(st.scale), ptr(st.shift),
+             n, og[0], og[1], og[2], sp.cout, self.act, self.slope, 1 if st.training else 0, ptr(dy), ptr(grads[self.bn.weight]), ptr(grads[self.bn.bias]),
+             ptr(ws))
+        sp.wgrad(dy, x, n, in_grid, self._dw(grads), lddy=sp.cout, db=grads[self.conv.bias] if self.conv.bias is not None else None)
+        if not need_dx:
+            return None
+        Min = n * in_grid[0] * in_grid[1] * in_grid[2]
+        dx = (zeros if sp.cin_mem != sp.cin else empty)(Min, sp.cin_mem, like=dp)
+        sp.dgrad(dy, n, in_grid, self._pack("d"), dx, lddy=sp.cout, lddx=sp.cin_mem)
+        return dx
+
     # the two places a layer that runs on a re-indexed weight (Refiner head) overrides
     def _pack(self, kind):
         return self.spec.pack_fwd(self.conv.weight) if kind == "f" else self.spec.pack_dgrad(self.conv.weight)

@@ -131,7 +131,7 @@ class Encoder(HipModule):
         return wp
 
     def _stem_fwd(self, images, I, tr):
-        """stem convolution + BatchNorm + ReLU + max-pool -> the 56 x 56 x 64 map.  Fused form (default, ops.set_stem_fused): the 112 x 112 x 64
+        """stem convolution + BatchNorm + ReLU + max-pool -> the 56 x 56 x 64 map.  Fused form (default, ops.set_bn_pool_fused): the 112 x 112 x 64
         activation between BatchNorm and pool is never stored (sv_bn_act_maxpool_fwd), nor is its gradient (sv_bn_maxpool_bwd)."""
         x16 = empty(I * 112 * 112, 16, like=images)                       # [.., (sy, sx, c)], channel 3 of every (sy, sx) group = 0
         call("sv_stem_space_to_depth", ptr(images), ptr(x16), I)
@@ -142,7 +142,7 @@ class Encoder(HipModule):
         st.finalize()
         mp = empty(I * 56 * 56, 64, like=x16)
         idx = torch.empty(I * 56 * 56 * 64, dtype=torch.uint8, device=x16.device)
-        fused = ops.stem_fused_enabled()
+        fused = ops.bn_pool_fused_enabled()
         if fused:
             st.probe(y, 64)
             call("sv_bn_act_maxpool_fwd", ptr(y), ptr(st.scale), ptr(st.shift), ptr(mp), ptr(idx), I, 112, 112, 64, ACT_RELU, 0.0)

@@ -22,7 +22,7 @@ class HeadConvBnAct(ConvBnAct):
         super().__init__(conv, bn, ConvSpec.conv3d(16, conv.out_channels, (4, 1, 1), 1, (2, 0, 0)), act, slope)
         self._w16 = self._dw16 = None
 
-    def forward(self, x, n, in_grid, training):
+    def _packed(self, x, n, in_grid):
         D = in_grid[0]
         assert tuple(in_grid) == (D, D, D)
         co = self.spec.cout
@@ -30,14 +30,30 @@ class HeadConvBnAct(ConvBnAct):
         call("sv_head_pack_x", ptr(x), ptr(xc), n, D)
         self._w16 = torch.empty(co, 16, 4, dtype=torch.float32, device=x.device)
         ops.transpose(self.conv.weight, self._w16, co, 4, 16)
+        return xc, D
+
+    def forward(self, x, n, in_grid, training):
+        xc, D = self._packed(x, n, in_grid)
         z, og, c = super().forward(xc, n, (D, D + 1, D + 1), training)
-        return z, og, (c, self._w16, D)
+        return z, og, (c, self._w16, D, n)
+
+    def forward_pool3d(self, x, n, in_grid, training):
+        xc, D = self._packed(x, n, in_grid)
+        p, og, c = super().forward_pool3d(xc, n, (D, D + 1, D + 1), training)
+        return p, og, (c, self._w16, D, n)
 
     def backward(self, ctx, dz, lddz, grads, *, need_dx=True):
-        c, self._w16, D = ctx
-        n, co = c[6], self.spec.cout
-        self._dw16 = torch.zeros(co, 16, 4, dtype=torch.float32, device=dz.device)
-        dxc = super().backward(c, dz, lddz, grads, need_dx=need_dx)
+        return self._backward(ctx, grads, need_dx, lambda c: ConvBnAct.backward(self, c, dz, lddz, grads, need_dx=need_dx))
+
+    def backward_pool3d(self, ctx, dp, grads, *, need_dx=True):
+        return self._backward(ctx, grads, need_dx, lambda c: ConvBnAct.backward_pool3d(self, c, dp, grads, need_dx=need_dx))
+
+    def _backward(self, ctx, grads, need_dx, inner):
+        c, self._w16, D, n = ctx
+        co = self.spec.cout
+        dev = self._w16.device
+        self._dw16 = torch.zeros(co, 16, 4, dtype=torch.float32, device=dev)
+        dxc = inner(c)
         # the weight gradient went out on the weight-gradient stream when a module backward runs one: its way back follows it there
         aw = ops._CTX.awg
         if aw is not None:
@@ -48,7 +64,7 @@ class HeadConvBnAct(ConvBnAct):
             ops.transpose(self._dw16, grads[self.conv.weight], co, 16, 4)
         if not need_dx:
             return None
-        dx = empty(n * D * D * D, 1, like=dz)
+        dx = empty(n * D * D * D, 1, like=dxc)
         call("sv_head_unpack_dx", ptr(dxc), ptr(dx), n, D)
         return dx
 
@@ -90,13 +106,19 @@ class Refiner(HipModule):
         B, tr = vol.shape[0], self.training
         v32 = ops.to_store(vol)                                            # [B,32,32,32,1] channels-last == planar
         x, g, dctx, skips = v32, (32, 32, 32), [], []
+        fused = ops.bn_pool_fused_enabled()
         for cba in self._down:
-            z, og, c = cba.forward(x, B, g, tr)                            # conv k4 p2 -> 33/17/9 grid, BN over all of it
             C = cba.spec.cout
+            if fused:                                                      # conv k4 p2 -> 33/17/9 grid, BN over all of it, pool in the same pass
+                p, og, c = cba.forward_pool3d(x, B, g, tr)
+                idx = None
+            else:
+                z, og, c = cba.forward(x, B, g, tr)
             pg = (og[0] // 2, og[1] // 2, og[2] // 2)
-            p = empty(B * pg[0] * pg[1] * pg[2], C, like=vol)
-            idx = torch.empty(p.numel(), dtype=torch.uint8, device=vol.device)
-            call("sv_maxpool3d_fwd", ptr(z), ptr(p), ptr(idx), B, og[0], og[1], og[2], C)
+            if not fused:
+                p = empty(B * pg[0] * pg[1] * pg[2], C, like=vol)
+                idx = torch.empty(p.numel(), dtype=torch.uint8, device=vol.device)
+                call("sv_maxpool3d_fwd", ptr(z), ptr(p), ptr(idx), B, og[0], og[1], og[2], C)
             dctx.append((c, og, idx))
             skips.append(p)
             x, g = p, pg
@@ -165,6 +187,9 @@ class Refiner(HipModule):
             dp = d_skip[li]
             if dx is not None:
                 call("sv_axpby", ptr(dp), ptr(dx), ptr(dp), 1.0, 1.0, dp.numel())
+            if idx is None:                                                # fused forward: the pool's backward runs inside the BatchNorm backward
+                dx = cba.backward_pool3d(c, dp, grads, need_dx=(li > 0 or in_needs[0]))
+                continue
             dz = empty(B * og[0] * og[1] * og[2], C, like=dout)
             call("sv_maxpool3d_bwd", ptr(dp), ptr(idx), ptr(dz), B, og[0], og[1], og[2], C)
             dx = cba.backward(c, dz, C, grads, need_dx=(li > 0 or in_needs[0]))

@@ -622,15 +622,16 @@ def set_bn_signs(on: bool) -> None:
     _STATE["bn_signs"] = bool(on)
 
 
-def stem_fused_enabled() -> bool:
+def bn_pool_fused_enabled() -> bool:
     import os
-    return _STATE.get("stem_fused", os.environ.get("SV_STEM_FUSED", "1") != "0")
+    return _STATE.get("bn_pool_fused", os.environ.get("SV_BN_POOL_FUSED", "1") != "0")
 
 
-def set_stem_fused(on: bool) -> None:
-    """A/B switch of the ResNet stem: True (default) = BatchNorm + ReLU + max-pool in one pass and the pool's backward inside the BatchNorm
-    backward (sv_bn_act_maxpool_fwd / sv_bn_maxpool_bwd), False = the separate passes."""
-    _STATE["stem_fused"] = bool(on)
+def set_bn_pool_fused(on: bool) -> None:
+    """A/B switch of the BatchNorm -> activation -> max-pool chains (ResNet stem, the Refiner's three down-sampling layers): True (default) =
+    one forward pass and the pool's backward inside the BatchNorm backward (sv_bn_act_maxpool*_fwd / sv_bn_maxpool*_bwd: neither the
+    activation nor its gradient is stored), False = the separate passes."""
+    _STATE["bn_pool_fused"] = bool(on)
 
 
 def set_conv_halo(mode: int) -> None:
