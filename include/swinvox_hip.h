@@ -329,6 +329,11 @@ int sv_swin_attn_block_bwd(const void* dx1, const void* qkv, const void* x, cons
  *  sv_stem_unpack_grad: dw [64,3,7,7] += dw16 [64][16][4][4];
  *  sv_merger_pack: w [cout][cin][27] fp32 -> bf16 forward pack [16][27][16 | 48] or data-gradient pack [16 | 48][27][16] (taps flipped);
  *                  concat = 1: the 36 input channels sit at columns 12 g + j of the four 12-wide planes.                              */
+/* Encoder input in one pass: images [I, 3, S, S] (fp32 when images_f32, else act_dtype; S % 4 == 0) -> x16 [I, S/2, S/2, 16] (the stem's space-to-depth
+ * image, as sv_stem_space_to_depth) and xp [I, S/4, S/4, 48] with xp[.., (ky, kx, c)] = images[c][4 py + ky][4 px + kx]: the rows on which timm's
+ * PatchEmbed Conv2d(3, C, kernel 4, stride 4) (behind reference models/swin_transformer.py:78) is a Linear(48, C) with the weight re-indexed
+ * [co][c][ky][kx] -> [co][(ky, kx, c)].  Replaces the fp32 -> storage cast, the NCHW -> NHWC transpose and sv_stem_space_to_depth. */
+int sv_encoder_prep(const void* images, int images_f32, void* x16, void* xp, int I, int S, int act_dtype, void* stream);
 /* Refiner head Conv3d(1, Co, k = 4, p = 2) on a D^3 grid (reference models/refiner.py:21-26) as a (4, 1, 1)-tap convolution over 16 channels (the stem's
  * trick): xc [N, D, D+1, D+1, 16] with xc[.., Y, X, 4 cy + cx] = x[.., Y + cy - 2, X + cx - 2] (zero outside); sv_head_unpack_dx folds the
  * 16-channel data gradient of that convolution back into dx [N, D, D, D]. */

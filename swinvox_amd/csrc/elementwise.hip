@@ -583,6 +583,49 @@ __global__ __launch_bounds__(256) void stem_s2d_kernel(const AT* __restrict__ im
     }
   }
 }
+// ---- encoder input in one pass: the NCHW renderings (fp32 as the module receives them, or the storage type) -> both backbones' first operands
+//   x16[i][oy][ox][(sy, sx, c)] = img[i][c][2 oy + sy][2 ox + sx]  (c < 3, 0 for c = 3)   the stem's space-to-depth image (stem_s2d_kernel)
+//   xp [i][py][px][(ky, kx, c)] = img[i][c][4 py + ky][4 px + kx]                           the Swin patch rows: PatchEmbed's Conv2d(3, C, 4, 4)
+//                                                                                            (timm, behind models/swin_transformer.py:78) is a Linear(48, C) on them
+// Both are rearrangements of the same 4 x 4 x 3 pixel block: one thread per block reads it once (12 row pieces of 4 pixels) and writes the 48
+// patch values and the four 16-value space-to-depth rows.  Replaces cast (fp32 -> storage) + NCHW -> NHWC transpose + space-to-depth, and the
+// 3-channel gathers of the patch-embedding convolution (6-byte taps on the engine's scalar path: 47 TFLOP/s forward, 53 weight gradient).
+template <typename IT, typename AT>
+__global__ __launch_bounds__(256) void encoder_prep_kernel(const IT* __restrict__ img, AT* __restrict__ x16, AT* __restrict__ xp, int S, long long n) {
+  const int P = S >> 2, Q = S >> 1;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+    const int px = (int)(t % P); long long r = t / P;
+    const int py = (int)(r % P); const long long i = r / P;
+    const IT* src = img + (i * 3) * S * S + (size_t)(4 * py) * S + 4 * px;
+    float v[3][4][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int ky = 0; ky < 4; ++ky) {
+        const float4 q = ld4f(src + ((size_t)c * S + ky) * S);
+        v[c][ky][0] = q.x; v[c][ky][1] = q.y; v[c][ky][2] = q.z; v[c][ky][3] = q.w;
+      }
+    AT* dp = xp + ((i * P + py) * P + px) * 48;
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {                     // 4 consecutive outputs (ky, kx, c) = 4 g .. 4 g + 3
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int e = 4 * g + j, ky = e / 12, kx = (e / 3) % 4, c = e % 3; o[j] = v[c][ky][kx]; }
+      st4f(dp + 4 * g, make_float4(o[0], o[1], o[2], o[3]));
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        AT* ds = x16 + ((i * Q + 2 * py + a) * Q + 2 * px + b) * 16;
+#pragma unroll
+        for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx)
+            st4f(ds + (sy * 2 + sx) * 4, make_float4(v[0][2 * a + sy][2 * b + sx], v[1][2 * a + sy][2 * b + sx], v[2][2 * a + sy][2 * b + sx], 0.f));
+      }
+  }
+}
 // wp[co][(ty, tx)][(sy, sx, c)] = w[co][c][2 ty + sy - 1][2 tx + sx - 1] inside the 7x7 kernel and c < 3, else 0
 template <typename WT>
 __global__ void stem_pack_kernel(const float* __restrict__ w, WT* __restrict__ wp) {
@@ -624,6 +667,18 @@ extern "C" int sv_stem_space_to_depth(const void* images, void* x16, int I, int 
   const long long n = (long long)I * 112 * 112 * 2;
   SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL(stem_s2d_kernel<AT>, dim3(grid_for(n)), dim3(256), 0, STREAM, CA(images), MA(x16), n););
   return check_launch("sv_stem_space_to_depth");
+}
+extern "C" int sv_encoder_prep(const void* images, int images_f32, void* x16, void* xp, int I, int S, int act_dtype, void* stream) {
+  SV_REQUIRE(images && x16 && xp && I > 0 && S >= 4 && S % 4 == 0, "encoder_prep: bad arguments (I=%d S=%d)", I, S);
+  SV_REQUIRE_ACT(act_dtype);
+  SV_REQUIRE((((uintptr_t)images | (uintptr_t)x16 | (uintptr_t)xp) & 15) == 0, "encoder_prep: buffers must be 16-byte aligned");
+  const long long n = (long long)I * (S / 4) * (S / 4);
+  if (images_f32) {
+    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL((encoder_prep_kernel<float, AT>), dim3(grid_for(n)), dim3(256), 0, STREAM, static_cast<const float*>(images), MA(x16), MA(xp), S, n););
+  } else {
+    SV_DISPATCH_ACT(act_dtype, hipLaunchKernelGGL((encoder_prep_kernel<AT, AT>), dim3(grid_for(n)), dim3(256), 0, STREAM, CA(images), MA(x16), MA(xp), S, n););
+  }
+  return check_launch("sv_encoder_prep");
 }
 extern "C" int sv_head_pack_x(const void* x, void* xc, int N, int D, int act_dtype, void* stream) {
   SV_REQUIRE(x && xc && N > 0 && D > 0, "head_pack_x: bad arguments");

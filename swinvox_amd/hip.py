@@ -52,7 +52,7 @@ _ACT_TYPED = {
     "sv_transpose", "sv_add_n", "sv_axpby", "sv_relu_bwd", "sv_maxpool2d_fwd", "sv_maxpool2d_bwd", "sv_avgpool2_fwd", "sv_avgpool2_bwd",
     "sv_decoder_seed_fwd", "sv_decoder_seed_bwd", "sv_maxpool3d_fwd", "sv_maxpool3d_bwd", "sv_dropout", "sv_rowscale",
     "sv_dwconv2x2_fwd", "sv_dwconv2x2_bwd", "sv_upsample3to7_add_fwd", "sv_upsample3to7_bwd", "sv_decoder_head_fwd", "sv_decoder_head_bwd",
-    "sv_merge_views_fwd", "sv_merge_views_bwd", "sv_stem_space_to_depth", "sv_bn_act_maxpool_fwd", "sv_bn_maxpool_bwd", "sv_bn_act_maxpool3d_fwd", "sv_bn_maxpool3d_bwd", "sv_head_pack_x", "sv_head_unpack_dx", "sv_swin_attn_block_fwd", "sv_swin_attn_block_bwd",
+    "sv_merge_views_fwd", "sv_merge_views_bwd", "sv_stem_space_to_depth", "sv_encoder_prep", "sv_bn_act_maxpool_fwd", "sv_bn_maxpool_bwd", "sv_bn_act_maxpool3d_fwd", "sv_bn_maxpool3d_bwd", "sv_head_pack_x", "sv_head_unpack_dx", "sv_swin_attn_block_fwd", "sv_swin_attn_block_bwd",
 }
 # argument lists WITHOUT the act_dtype / stream tail (added in load())
 _PROTOS = {
@@ -97,6 +97,7 @@ _PROTOS = {
     "sv_set_conv_halo": (_I, None, [_I]),
     "sv_conv_halo_mode": (_I, None),
     "sv_conv_halo_launches": (_L, None),
+    "sv_encoder_prep": (_I, [_P, _I, _P, _P, _I, _I]),
     "sv_head_pack_x": (_I, [_P, _P, _I, _I]),
     "sv_head_unpack_dx": (_I, [_P, _P, _I, _I]),
     "sv_stem_pack": (_I, [_P, _P, _I]),

@@ -130,11 +130,12 @@ class Encoder(HipModule):
         call("sv_stem_pack", ptr(self.resnet[0].weight), ptr(wp), ops.hip.ACT)
         return wp
 
-    def _stem_fwd(self, images, I, tr):
+    def _stem_fwd(self, images, I, tr, x16=None):
         """stem convolution + BatchNorm + ReLU + max-pool -> the 56 x 56 x 64 map.  Fused form (default, ops.set_bn_pool_fused): the 112 x 112 x 64
         activation between BatchNorm and pool is never stored (sv_bn_act_maxpool_fwd), nor is its gradient (sv_bn_maxpool_bwd)."""
-        x16 = empty(I * 112 * 112, 16, like=images)                       # [.., (sy, sx, c)], channel 3 of every (sy, sx) group = 0
-        call("sv_stem_space_to_depth", ptr(images), ptr(x16), I)
+        if x16 is None:
+            x16 = empty(I * 112 * 112, 16, like=images)                   # [.., (sy, sx, c)], channel 3 of every (sy, sx) group = 0
+            call("sv_stem_space_to_depth", ptr(images), ptr(x16), I)
         sp, bn, M = self._stem_spec, self.resnet[1], I * 112 * 112
         y = empty(M, 64, like=x16)
         st = BatchNormState(bn, M, tr)
@@ -173,21 +174,29 @@ class Encoder(HipModule):
     def _fwd(self, images, save):
         B, V = images.shape[:2]
         I = B * V
-        images = ops.to_store(images)                                      # fp32 module input -> storage dtype
+        prep = ops.input_prep_enabled() and self.swin_transformer.model.embed_lin.cin == 48
+        if not prep:
+            images = ops.to_store(images)                                  # fp32 module input -> storage dtype
         tr, sto = self.training, self.stochastic
         seeds = self._seed
         multi = self.cfg.NETWORK.USE_SWIN_T_MULTI_STAGE
-        img = empty(I, 224 * 224, 3, like=images)
-        ops.transpose(images, img, I, 3, 224 * 224)                       # NCHW -> NHWC (coalesced both ways)
-        cat = empty(I * 49, 512, like=img)                                 # [resnet 256 | swin 256] concat buffer
+        x16 = xp = img = None
+        if prep:    # one pass over the renderings as they arrive: the stem's space-to-depth image and the Swin patch rows (no cast, no transpose)
+            images = images.contiguous()
+            x16, xp = empty(I * 112 * 112, 16, like=images), empty(I * 56 * 56, 48, like=images)
+            call("sv_encoder_prep", ptr(images), 1 if images.dtype == torch.float32 else 0, ptr(x16), ptr(xp), I, 224)
+        else:
+            img = empty(I, 224 * 224, 3, like=images)
+            ops.transpose(images, img, I, 3, 224 * 224)                   # NCHW -> NHWC (coalesced both ways)
+        cat = empty(I * 49, 512, like=images)                              # [resnet 256 | swin 256] concat buffer
         main = torch.cuda.current_stream()
-        side = ops.side_stream(img.device) if ops.overlap_enabled() else main
+        side = ops.side_stream(images.device) if ops.overlap_enabled() else main
         side.wait_stream(main)                                             # fork: the Swin backbone runs beside the ResNet trunk
         ready = []
         with torch.cuda.stream(side):
-            feats, swin_tape = swin_forward(self.swin_transformer, img, I, tr, sto, seeds, ready, save)
+            feats, swin_tape = swin_forward(self.swin_transformer, img, I, tr, sto, seeds, ready, save, patches=xp)
         # ---- ResNet trunk
-        x, g, c_stem = self._stem_fwd(images, I, tr)                       # stem conv + BatchNorm + ReLU + max-pool
+        x, g, c_stem = self._stem_fwd(images, I, tr, x16)                  # stem conv + BatchNorm + ReLU + max-pool
         c_blocks = []
         for li in (4, 5, 6):
             for blk in self.resnet[li]:

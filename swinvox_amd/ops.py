@@ -622,6 +622,17 @@ def set_bn_signs(on: bool) -> None:
     _STATE["bn_signs"] = bool(on)
 
 
+def input_prep_enabled() -> bool:
+    import os
+    return _STATE.get("input_prep", os.environ.get("SV_INPUT_PREP", "1") != "0")
+
+
+def set_input_prep(on: bool) -> None:
+    """A/B switch of the encoder's input: True (default) = sv_encoder_prep (renderings -> stem space-to-depth image + Swin patch rows in one
+    pass, patch embedding as a Linear(48, C)), False = cast + NCHW -> NHWC transpose + sv_stem_space_to_depth + the 4 x 4 / stride-4 convolution."""
+    _STATE["input_prep"] = bool(on)
+
+
 def bn_pool_fused_enabled() -> bool:
     import os
     return _STATE.get("bn_pool_fused", os.environ.get("SV_BN_POOL_FUSED", "1") != "0")
