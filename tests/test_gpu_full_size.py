@@ -167,8 +167,9 @@ def test_train_step_statistics_and_determinism_at_the_bench_shape(dev, big):
             assert float(b.abs().sum()) == 0.0, k
             continue
         # analytically-zero gradients (a conv bias in front of a train-mode BatchNorm: the sum of the BatchNorm's input gradient) are
-        # rounding residue of the order 1e-7 of the layer's weight gradient - compared absolutely
-        if float(a.abs().max()) < 1e-5:
+        # rounding residue of the order 1e-7 of the layer's weight gradient - compared absolutely (Merger.layer5.0.bias sits at 1-2e-5 and
+        # differed by 1.1e-5 of itself in one run: float atomics of the stencil weight gradient)
+        if float(a.abs().max()) < 1e-4:
             assert float((a - b).abs().max()) < 1e-6, k
             continue
         e = float((a - b).abs().sum()) / den
