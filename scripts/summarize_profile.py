@@ -21,8 +21,9 @@ def family(name: str) -> str:
         for k in ("swin_mlp_fwd_kernel", "swin_mlp_bwd_kernel", "swin_mlp_wgrad_kernel", "swin_mlp_pack_kernel"):
             if k in n:
                 return "fused Swin MLP: " + k
-    if "igemm_kernel" in n or ("wgrad_kernel" in n and "stencil" not in n) or "gemm_dense_kernel" in n or "gemm_wide_kernel" in n or "wgrad_wide_kernel" in n:
-        return "contraction engine (igemm_kernel + gemm_dense_kernel + gemm_wide_kernel + wgrad_kernel + wgrad_wide_kernel)"
+    if ("igemm_kernel" in n or ("wgrad_kernel" in n and "stencil" not in n) or "gemm_dense_kernel" in n or "gemm_wide_kernel" in n or "wgrad_wide_kernel" in n
+            or "conv_halo_kernel" in n):     # the halo-tile kernels run behind the same entry points (sv_conv_gather / sv_tconv_gather)
+        return "contraction engine (igemm_kernel + gemm_dense_kernel + gemm_wide_kernel + conv_halo_kernel + wgrad_kernel + wgrad_wide_kernel)"
     if "swin_attn_block_fwd" in n:
         return "fused Swin attention branch forward (swin_attn_block_fwd_kernel)"
     if "swin_attn_block_bwd" in n:
@@ -31,8 +32,8 @@ def family(name: str) -> str:
         return "window attention forward (win_attn_fwd_*)"
     if "win_attn_bwd" in n:
         return "window attention backward (win_attn_bwd_*)"
-    if "bn_bwd" in n or "scale_shift_act" in n or "bn_finalize" in n or "bn_stats" in n:
-        return "BatchNorm passes (bn_bwd_* + scale_shift_act_* + bn_finalize + bn_stats)"
+    if "bn_bwd" in n or "scale_shift_act" in n or "bn_finalize" in n or "bn_stats" in n or "bn_act_maxpool" in n or "bn_pool" in n:
+        return "BatchNorm passes (bn_bwd_* + scale_shift_act_* + bn_finalize + bn_stats + the passes fused with a max-pool: bn_act_maxpool*, bn_pool*_bwd_*)"
     if "ln_fwd" in n or "ln_bwd" in n or "lnl_" in n:
         return "LayerNorm passes (ln_* + lnl_*)"
     if "stencil3" in n:
