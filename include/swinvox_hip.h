@@ -90,6 +90,8 @@ int sv_conv_gather(const void* in, const void* w_packed, void* out, const sv_geo
  * calls of >= 256 tiles of 8 x 32 positions, 2: every call of those shapes.  Results differ from the gather engine's only in fp32 summation order. */
 int sv_set_conv_halo(int mode);
 int sv_conv_halo_mode(void);
+int sv_set_conv_halo_wgrad(int mode); /* the same switch for the halo-tile WEIGHT gradient of the 3 x 3 / stride 1 convolutions with 64 k channels on both
+                                         sides behind sv_conv_wgrad (SV_CONV_HALO_WGRAD; 1 = calls of >= 4 tiles per split) */
 long long sv_conv_halo_launches(void); /* calls taken by the halo-tile kernels so far in this process (tests: the path they mean to exercise) */
 /* 1 when sv_conv_gather would run this call on the wide dense kernel (256 x 128 tile, LDS-DMA operand ring: Linear / 1x1 layers with
  * bf16 storage, K % 32 == 0, K >= 128, Co >= 128, 8-aligned rows and >= 256 tiles), else 0.  SV_GEMM_WIDE=0 in the environment disables it. */

@@ -308,6 +308,147 @@ static std::atomic<int>& halo_mode() {
   static std::atomic<int> m{[] { const char* v = getenv("SV_CONV_HALO"); return v ? atoi(v) : 1; }()};
   return m;
 }
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the 3 x 3 / stride 1 / padding 1 convolutions with 64 k input and output channels (conv2 of the ResNet bottlenecks):
+//   dW[co][tap][ci] = sum over positions of dy[pos][co] * x[pos + tap - 1][ci]
+// wgrad_kernel treats it as a GEMM with 9 Ci gathered columns and re-reads the position tiles of x and dy once per 128 x 128 output tile:
+// 18 times each at 256 channels (L2 -> LDS fill bound: 320-510 TFLOP/s).  Here a workgroup owns ONE 64 x 64 (co, ci) block for ALL nine taps -
+// 9 x 16 accumulator registers per lane, wave w the 32 x 32 sub-block (w / 2, w % 2) - and walks a range of 8 x 32-position tiles: per tile
+// the 64-channel slice of the x patch (with halo, 43.5 KB) and of the dy tile (32 KB) go global -> registers -> LDS once, and every tap is a
+// shifted view of the same patch.  x and dy are read Co / 64 and Ci / 64 times in total (4 x at 256 channels).  Both MFMA operands need 8
+// consecutive POSITIONS per lane from [position][channel] images: ds_read_b64_tr_b16 (two 4 x 16 transposing reads per 32 x 16 fragment);
+// the 64-byte halves of a row are swapped on rows with bit 1 set, so that the four rows a 32-lane half reads cover all 64 banks; every
+// fragment address is a lane constant + a compile-time offset.  The fp32 block is added once per workgroup to the packed workspace
+// [Co][9][Ci] of sv_conv_wgrad (128 contiguous bytes per atomic instruction), which the caller unpacks as before.
+// ------------------------------------------------------------------------------------------------
+struct HaloWgradArgs { const void* x; const void* dy; float* ws; int N, H, W, Ci, Co; };
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_h;
+
+// TH x TW = 8 x 32 or 16 x 16 positions per tile (256 either way: sixteen K steps of 16 positions in one tile row), whichever wastes less of the
+// image: 56^2 -> 8 x 32 (87 % of the tile positions inside the image), 14^2 -> 16 x 16 (77 % against 38 %)
+template <int TH, int TW>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_kernel(const HaloWgradArgs p, int tiles_h, int tiles_w, int ntiles, int nsplit) {
+  static_assert(TH * TW == 256 && TW % 16 == 0, "tile = 256 positions in rows of 16 k");
+  constexpr int PW = TW + 2, NPOS = (TH + 2) * PW, NXC = NPOS * 8, NXL = (NXC + 255) / 256, NDL = TH * TW * 8 / 256;
+  constexpr int X_BYTES = NPOS * 128, D_BYTES = TH * TW * 128;
+  __shared__ __attribute__((aligned(1024))) char smem[X_BYTES + D_BYTES];
+  char* Xl = smem;
+  char* Dl = smem + X_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H, Wd = p.W, Ci = p.Ci, Co = p.Co;
+  // workgroup -> (split, output block): the workgroups of one XCD (blockIdx.x % 8) take consecutive splits and all output blocks of a split -
+  // they read the same position tiles, once from HBM into that XCD's L2
+  const int nci = Ci >> 6, nob = nci * (Co >> 6);
+  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3, spx = nsplit >> 3;
+  const int split = xcd * spx + li / nob, ob = li % nob;
+  const int cob = ob / nci, cib = ob - cob * nci;
+  const int t0 = (int)((long long)ntiles * split / nsplit), t1 = (int)((long long)ntiles * (split + 1) / nsplit);
+  if (t0 >= t1) return;
+
+  const unsigned xbytes = (unsigned)p.N * H * Wd * Ci * 2, dbytes = (unsigned)p.N * H * Wd * Co * 2;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, dbytes, 0x00020000);
+  const int tpi = tiles_h * tiles_w;
+  // per-thread constants of its chunks (16 bytes = 8 channels of one position)
+  int xpr[NXL], xpc[NXL];
+  unsigned xrel[NXL];
+#pragma unroll
+  for (int j = 0; j < NXL; ++j) {
+    const int c = tid + 256 * j, pp = c >> 3, sc = c & 7;
+    xpr[j] = pp / PW - 1; xpc[j] = pp % PW - 1;
+    xrel[j] = (unsigned)(((xpr[j] * Wd + xpc[j]) * Ci + cib * 64 + sc * 8) * 2);
+  }
+  u32x4 xpre[NXL], dpre[NDL];
+  auto load_tile = [&](int t) {
+    const int n = t / tpi, r = t - n * tpi, th = r / tiles_w, h0 = th * TH, w0 = (r - th * tiles_w) * TW;
+    const unsigned pos0 = (unsigned)((n * H + h0) * Wd + w0);
+#pragma unroll
+    for (int j = 0; j < NXL; ++j) {
+      const bool ok = (unsigned)(h0 + xpr[j]) < (unsigned)H && (unsigned)(w0 + xpc[j]) < (unsigned)Wd;
+      xpre[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, (pos0 * Ci * 2 + xrel[j]) | ((unsigned)!ok << 31), 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NDL; ++j) {
+      const int c = tid + 256 * j, q = c >> 3, sc = c & 7, rr = q / TW, cc = q % TW;
+      const bool ok = h0 + rr < H && w0 + cc < Wd;          // positions of the tile outside the image contribute nothing
+      dpre[j] = __builtin_amdgcn_raw_buffer_load_b128(dr, ((pos0 + rr * Wd + cc) * Co * 2 + (cob * 64 + sc * 8) * 2) | ((unsigned)!ok << 31), 0, 0);
+    }
+  };
+  auto store_tile = [&]() {               // 16-byte slot s of row r -> s ^ 4 on rows with bit 1 set (the 64-byte halves swapped)
+#pragma unroll
+    for (int j = 0; j < NXL; ++j) {
+      const int c = tid + 256 * j, pp = c >> 3, sc = c & 7;
+      if (NXC % 256 == 0 || c < NXC) *reinterpret_cast<u32x4*>(Xl + pp * 128 + ((sc ^ ((pp & 2) << 1)) << 4)) = xpre[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NDL; ++j) {
+      const int c = tid + 256 * j, q = c >> 3, sc = c & 7;
+      *reinterpret_cast<u32x4*>(Dl + q * 128 + ((sc ^ ((q & 2) << 1)) << 4)) = dpre[j];
+    }
+  };
+
+  // fragment addressing (32x32x16: lane = column l & 31 of the block, k = 8 (l >> 5) ..; per 16-lane group a 4 x 16 transposing read)
+  const int mb = wave >> 1, nb = wave & 1, g = lane >> 4, lr = lane & 15, q4 = lr >> 2, pq = lr & 3;
+  const int arow = 8 * (g >> 1) + q4;                                   // + 16 s + 4 hi
+  const char* abase = Dl + arow * 128 + ((mb ^ (q4 >> 1)) << 6) + 32 * (g & 1) + 8 * pq;
+  const char* bbase[3][2];                                               // [kw][parity of the patch row r + kh]
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    const int half = nb ^ (((kw + q4) >> 1) & 1);
+#pragma unroll
+    for (int par = 0; par < 2; ++par) bbase[kw][par] = Xl + arow * 128 + ((half ^ par) << 6) + 32 * (g & 1) + 8 * pq;
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+  load_tile(t0);
+  store_tile();
+  __syncthreads();
+  for (int t = t0; t < t1; ++t) {
+    if (t + 1 < t1) load_tile(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {      // 16 positions per step: tile row s / 2, columns 16 (s % 2) ..
+      const int r = s_ / (TW / 16), c0 = 16 * (s_ % (TW / 16));
+      const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)(abase + (16 * s_) * 128));
+      const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)(abase + (16 * s_ + 4) * 128));
+      const bf16x8 a = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const char* bp = bbase[kw][(r + kh) & 1] + ((r + kh) * PW + c0 + kw) * 128;
+          const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)(bp));
+          const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)(bp + 4 * 128));
+          const bf16x8 b = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[kh * 3 + kw], 0, 0, 0);
+        }
+    }
+    __syncthreads();                       // every wave is done with the images
+    if (t + 1 < t1) store_tile();
+    __syncthreads();
+  }
+  // dW block: lane = ci column l & 31, register j = co row (j & 3) + 8 (j >> 2) + 4 (l >> 5) of the 32 x 32 sub-block
+  float* wsb = p.ws + ((size_t)(cob * 64 + mb * 32) * 9) * Ci + cib * 64 + nb * 32 + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int co = (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+      atomicAdd(wsb + ((size_t)co * 9 + t) * Ci, acc[t][j]);
+    }
+}
+
+static std::atomic<int>& halo_wgrad_mode() {
+  static std::atomic<int> m{[] { const char* v = getenv("SV_CONV_HALO_WGRAD"); return v ? atoi(v) : 1; }()};
+  return m;
+}
+
 static std::atomic<long long> halo_launches{0};
 bool conv_halo_enabled() { return halo_mode().load(std::memory_order_relaxed) != 0; }
 
@@ -325,6 +466,31 @@ int conv_halo_launch(const HaloConvArgs& a, int kind, hipStream_t stream) {
     hipLaunchKernelGGL((conv_halo_kernel<64, 3, 3, 1, 1>), dim3(256), dim3(256), 0, stream, a, tiles_h, tiles_w, ntiles, ctr);
   else   // 32 KB of weights + 18 KB patch + 16 KB staging: two workgroups per CU - one's epilogue runs under the other's MFMAs
     hipLaunchKernelGGL((conv_halo_kernel<16, 4, 4, 2, 2>), dim3(512), dim3(256), 0, stream, a, tiles_h, tiles_w, ntiles, ctr);
+  halo_launches.fetch_add(1, std::memory_order_relaxed);
+  return 1;
+}
+
+// 3 x 3 / stride 1 / padding 1 weight gradient into the packed workspace ws [Co][9][Ci] (zero on entry); 1 = taken
+int conv_halo_wgrad_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, hipStream_t stream) {
+  const int mode = halo_wgrad_mode().load(std::memory_order_relaxed);
+  if (mode == 0 || (Ci & 63) || (Co & 63)) return 0;
+  const long long big = (long long)N * H * W * (Ci > Co ? Ci : Co) * 2;
+  if (big >= (1ll << 31)) return 0;
+  // tile shape by the share of tile positions that lie inside the image
+  const double u0 = (double)H * W / ((double)cdiv(H, 8) * 8 * cdiv(W, 32) * 32), u1 = (double)H * W / ((double)cdiv(H, 16) * 16 * cdiv(W, 16) * 16);
+  const bool sq = u1 > u0;
+  if (mode == 1 && (sq ? u1 : u0) < 0.5) return 0;          // small maps (7 x 7): most of every tile would be padding
+  const int tiles_h = cdiv(H, sq ? 16 : 8), tiles_w = cdiv(W, sq ? 16 : 32);
+  const long long nt = (long long)N * tiles_h * tiles_w;
+  const int nob = (Ci >> 6) * (Co >> 6);
+  // splits: a multiple of 8 (one group of consecutive splits per XCD), about one workgroup per CU, at least 4 tiles per split
+  int nsplit = 256 / nob; nsplit = nsplit / 8 * 8;
+  if (nsplit < 8) nsplit = 8;
+  if (mode == 1 && nt < 4ll * nsplit) return 0;
+  if (nt >= (1ll << 30)) return 0;
+  HaloWgradArgs a{x, dy, ws, N, H, W, Ci, Co};
+  if (sq) hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<16, 16>), dim3(nsplit * nob), dim3(256), 0, stream, a, tiles_h, tiles_w, (int)nt, nsplit);
+  else hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<8, 32>), dim3(nsplit * nob), dim3(256), 0, stream, a, tiles_h, tiles_w, (int)nt, nsplit);
   halo_launches.fetch_add(1, std::memory_order_relaxed);
   return 1;
 }
@@ -348,3 +514,8 @@ extern "C" int sv_conv_halo_prof(long long* out, int reset) {
   return 0;
 }
 #endif
+extern "C" int sv_set_conv_halo_wgrad(int mode) {
+  SV_REQUIRE(mode >= 0 && mode <= 2, "sv_set_conv_halo_wgrad: mode %d (0 off, 1 auto, 2 always)", mode);
+  sv::halo_wgrad_mode().store(mode, std::memory_order_relaxed);
+  return SV_OK;
+}

@@ -96,6 +96,7 @@ _PROTOS = {
     "sv_bn_maxpool3d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P]),
     "sv_set_conv_halo": (_I, None, [_I]),
     "sv_conv_halo_mode": (_I, None),
+    "sv_set_conv_halo_wgrad": (_I, None, [_I]),
     "sv_conv_halo_launches": (_L, None),
     "sv_encoder_prep": (_I, [_P, _I, _P, _P, _I, _I]),
     "sv_head_pack_x": (_I, [_P, _P, _I, _I]),

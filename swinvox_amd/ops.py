@@ -653,6 +653,14 @@ def set_conv_halo(mode: int) -> None:
         raise RuntimeError(f"sv_set_conv_halo failed (rc={rc}): {hip.load().sv_last_error().decode()}")
 
 
+def set_conv_halo_wgrad(mode: int) -> None:
+    """Halo-tile weight gradient of the 3 x 3 / stride-1 convolutions with 64 k channels (csrc/conv_halo.hip) behind sv_conv_wgrad: 0 off,
+    1 from 4 tiles per split on (default), 2 always.  Process-wide; SV_CONV_HALO_WGRAD sets the initial mode."""
+    rc = hip.load().sv_set_conv_halo_wgrad(int(mode))
+    if rc != 0:
+        raise RuntimeError(f"sv_set_conv_halo_wgrad failed (rc={rc}): {hip.load().sv_last_error().decode()}")
+
+
 def set_bn_probe(fn) -> None:
     """Debug hook of the tests: fn(state, stored_output, ld) is called for every BatchNorm layer right before its normalisation pass,
     when `state.sums` (the [BN_SLOTS][2C] double partial sums the producing kernel's epilogue accumulated) and the producer's stored
