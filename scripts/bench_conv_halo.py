@@ -36,16 +36,17 @@ for name, sp, H, ci, k in (("3x3 64->64 @56", ConvSpec.conv2d(64, 64, 3, 1, 1), 
             line += f"   data gradient {td:7.1f} us ({flops / td / 1e6:6.1f} TF/s)"
         print(line)
 # ---- weight gradient of the 3 x 3 / stride 1 convolutions (sv_conv_wgrad): wgrad_kernel against the halo-tile kernel
-for H, C in ((56, 64), (28, 128), (14, 256), (7, 256)):
-    sp = ConvSpec.conv2d(C, C, 3, 1, 1)
-    M = n * H * H
+for H, C, st in ((56, 64, 1), (28, 128, 1), (14, 256, 1), (7, 256, 1), (56, 256, 2), (28, 256, 2), (56, 128, 2), (14, 256, 2)):
+    sp = ConvSpec.conv2d(C, C, 3, st, 1)
+    Ho = (H - 1) // st + 1
+    M, Mo = n * H * H, n * Ho * Ho
     x = torch.randn(M, C, device=dev).bfloat16()
-    dy = torch.randn(M, C, device=dev).bfloat16()
-    dw = torch.zeros(C, C, 3, 3, device=dev)
-    flops = 2.0 * M * 9 * C * C
-    line = f"3x3 {C:3d}->{C:3d} @{H:2d} weight gradient:"
+    dy = torch.randn(Mo, C, device=dev).bfloat16()
+    dw, db = torch.zeros(C, C, 3, 3, device=dev), torch.zeros(C, device=dev)
+    flops = 2.0 * Mo * 9 * C * C
+    line = f"3x3 {C:3d}->{C:3d} @{H:2d} stride {st} weight gradient{' + bias' if st == 2 else ''}:"
     for mode in (0, 2):
         ops.set_conv_halo_wgrad(mode)
-        t = timeit(lambda: sp.wgrad(dy, x, n, (1, H, H), dw))
+        t = timeit(lambda: sp.wgrad(dy, x, n, (1, H, H), dw, db=db if st == 2 else None))
         line += f"   mode {mode}: {t:7.1f} us ({flops / t / 1e6:6.1f} TF/s)"
     print(line)

@@ -18,9 +18,10 @@ struct HaloConvArgs {
 int conv_halo_launch(const HaloConvArgs& a, int kind, hipStream_t stream);
 bool conv_halo_enabled();
 
-// 3 x 3 / stride 1 / padding 1 weight gradient (Ci, Co multiples of 64, rows of exactly Ci / Co elements) into the packed workspace
-// ws [Co][9][Ci] fp32 (zero on entry); 1 = taken, 0 = not this kernel's shape or switched off
-int conv_halo_wgrad_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, hipStream_t stream);
+// 3 x 3 / padding 1 / stride 1 or 2 weight gradient (Ci, Co multiples of 64, rows of exactly Ci / Co elements) into the packed workspace
+// ws [Co][9][Ci] fp32 (zero on entry), dbias (optional) += column sums of dy; 1 = taken, 0 = not this kernel's shape or switched off
+int conv_halo_wgrad_launch(const void* x, const void* dy, float* ws, float* dbias, int N, int H, int W, int Ho, int Wo, int stride, int Ci, int Co,
+                           hipStream_t stream);
 
 // launch slot of the run-time tile schedulers (igemm.hip): 16 ints, zero on entry, zeroed again by the launch's last workgroup
 int* tile_draw_counters();

@@ -325,13 +325,17 @@ struct HaloWgradArgs { const void* x; const void* dy; float* ws; int N, H, W, Ci
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_h;
 
-// TH x TW = 8 x 32 or 16 x 16 positions per tile (256 either way: sixteen K steps of 16 positions in one tile row), whichever wastes less of the
-// image: 56^2 -> 8 x 32 (87 % of the tile positions inside the image), 14^2 -> 16 x 16 (77 % against 38 %)
-template <int TH, int TW>
-__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_kernel(const HaloWgradArgs p, int tiles_h, int tiles_w, int ntiles, int nsplit) {
-  static_assert(TH * TW == 256 && TW % 16 == 0, "tile = 256 positions in rows of 16 k");
-  constexpr int PW = TW + 2, NPOS = (TH + 2) * PW, NXC = NPOS * 8, NXL = (NXC + 255) / 256, NDL = TH * TW * 8 / 256;
-  constexpr int X_BYTES = NPOS * 128, D_BYTES = TH * TW * 128;
+// TH x TW output positions per tile, rows of 16 k (one K step = 16 positions of a tile row).  Stride 1: 8 x 32 or 16 x 16 (256 positions),
+// whichever wastes less of the image - 56^2 -> 8 x 32 (87 % of the tile positions inside the image), 14^2 -> 16 x 16 (77 % against 38 %).
+// Stride 2 (S = 2): 8 x 16 outputs from a 17 x 33 input patch (72 KB); a fragment's 8 positions are every second patch row.
+// dbias (optional): column sums of dy - a tenth accumulator fed with an all-ones B operand in the workgroups of the first ci block.
+template <int TH, int TW, int S, bool BIAS>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_kernel(const HaloWgradArgs p, int Ho, int Wo, int tiles_h, int tiles_w, int ntiles, int nsplit,
+                                                                    float* __restrict__ dbias) {
+  static_assert(TW % 16 == 0 && (TH * TW) % 32 == 0, "tile rows of 16 k");
+  constexpr int NQ = TH * TW, NKS = NQ / 16, PW = S * (TW - 1) + 3, PH = S * (TH - 1) + 3, NPOS = PH * PW;
+  constexpr int NXC = NPOS * 8, NXL = (NXC + 255) / 256, NDL = NQ * 8 / 256;
+  constexpr int X_BYTES = NPOS * 128, D_BYTES = NQ * 128;
   __shared__ __attribute__((aligned(1024))) char smem[X_BYTES + D_BYTES];
   char* Xl = smem;
   char* Dl = smem + X_BYTES;
@@ -345,8 +349,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_kernel(const HaloWg
   const int cob = ob / nci, cib = ob - cob * nci;
   const int t0 = (int)((long long)ntiles * split / nsplit), t1 = (int)((long long)ntiles * (split + 1) / nsplit);
   if (t0 >= t1) return;
+  const bool bias = BIAS && cib == 0;
 
-  const unsigned xbytes = (unsigned)p.N * H * Wd * Ci * 2, dbytes = (unsigned)p.N * H * Wd * Co * 2;
+  const unsigned xbytes = (unsigned)p.N * H * Wd * Ci * 2, dbytes = (unsigned)p.N * Ho * Wo * Co * 2;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, dbytes, 0x00020000);
   const int tpi = tiles_h * tiles_w;
@@ -361,18 +366,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_kernel(const HaloWg
   }
   u32x4 xpre[NXL], dpre[NDL];
   auto load_tile = [&](int t) {
-    const int n = t / tpi, r = t - n * tpi, th = r / tiles_w, h0 = th * TH, w0 = (r - th * tiles_w) * TW;
-    const unsigned pos0 = (unsigned)((n * H + h0) * Wd + w0);
+    const int n = t / tpi, r = t - n * tpi, th = r / tiles_w, h0 = th * TH, w0 = (r - th * tiles_w) * TW;     // output tile origin
+    const unsigned xpos0 = (unsigned)((n * H + S * h0) * Wd + S * w0), dpos0 = (unsigned)((n * Ho + h0) * Wo + w0);
 #pragma unroll
     for (int j = 0; j < NXL; ++j) {
-      const bool ok = (unsigned)(h0 + xpr[j]) < (unsigned)H && (unsigned)(w0 + xpc[j]) < (unsigned)Wd;
-      xpre[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, (pos0 * Ci * 2 + xrel[j]) | ((unsigned)!ok << 31), 0, 0);
+      const bool ok = (unsigned)(S * h0 + xpr[j]) < (unsigned)H && (unsigned)(S * w0 + xpc[j]) < (unsigned)Wd;
+      xpre[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, (xpos0 * Ci * 2 + xrel[j]) | ((unsigned)!ok << 31), 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < NDL; ++j) {
       const int c = tid + 256 * j, q = c >> 3, sc = c & 7, rr = q / TW, cc = q % TW;
-      const bool ok = h0 + rr < H && w0 + cc < Wd;          // positions of the tile outside the image contribute nothing
-      dpre[j] = __builtin_amdgcn_raw_buffer_load_b128(dr, ((pos0 + rr * Wd + cc) * Co * 2 + (cob * 64 + sc * 8) * 2) | ((unsigned)!ok << 31), 0, 0);
+      const bool ok = h0 + rr < Ho && w0 + cc < Wo;         // positions of the tile outside the image contribute nothing
+      dpre[j] = __builtin_amdgcn_raw_buffer_load_b128(dr, ((dpos0 + rr * Wo + cc) * Co * 2 + (cob * 64 + sc * 8) * 2) | ((unsigned)!ok << 31), 0, 0);
     }
   };
   auto store_tile = [&]() {               // 16-byte slot s of row r -> s ^ 4 on rows with bit 1 set (the 64-byte halves swapped)
@@ -388,19 +393,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_kernel(const HaloWg
     }
   };
 
-  // fragment addressing (32x32x16: lane = column l & 31 of the block, k = 8 (l >> 5) ..; per 16-lane group a 4 x 16 transposing read)
+  // fragment addressing (32x32x16: lane = column l & 31 of the block, k = 8 (l >> 5) ..; per 16-lane group a 4 x 16 transposing read).
+  // Row of the image a lane addresses = (lane part) + (compile-time part); which 64-byte half of the row holds its columns depends on bit 1 of
+  // that row: bit 1 of the lane part's low bits XOR bit 1 of the compile-time part - two bases per kw, picked at compile time.
   const int mb = wave >> 1, nb = wave & 1, g = lane >> 4, lr = lane & 15, q4 = lr >> 2, pq = lr & 3;
-  const int arow = 8 * (g >> 1) + q4;                                   // + 16 s + 4 hi
+  const int arow = 8 * (g >> 1) + q4;                                   // dy image: + 16 s + 4 hi
   const char* abase = Dl + arow * 128 + ((mb ^ (q4 >> 1)) << 6) + 32 * (g & 1) + 8 * pq;
-  const char* bbase[3][2];                                               // [kw][parity of the patch row r + kh]
+  // x patch: fragment position kk = 8 (g >> 1) + q4 + 4 hi of the K step -> patch row (S r + kh) PW + S (c0 + kk) + kw
+  const char* bbase[3][2];                                               // [kw][bit 1 of the compile-time part]
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw) {
-    const int half = nb ^ (((kw + q4) >> 1) & 1);
+    const int lanebit = S == 1 ? (((kw + q4) >> 1) & 1) : (q4 & 1);      // S = 2: row = C + 2 q4 + ...: bit 1 = bit1(C) ^ (q4 & 1)
+    const int half = nb ^ lanebit;
 #pragma unroll
-    for (int par = 0; par < 2; ++par) bbase[kw][par] = Xl + arow * 128 + ((half ^ par) << 6) + 32 * (g & 1) + 8 * pq;
+    for (int par = 0; par < 2; ++par) bbase[kw][par] = Xl + (S * arow) * 128 + ((half ^ par) << 6) + 32 * (g & 1) + 8 * pq;
   }
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.f;
 
-  f32x16 acc[9];
+  f32x16 acc[9], accb;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) accb[j] = 0.f;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -413,18 +427,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_kernel(const HaloWg
     if (t + 1 < t1) load_tile(t + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s_ = 0; s_ < 16; ++s_) {      // 16 positions per step: tile row s / 2, columns 16 (s % 2) ..
+    for (int s_ = 0; s_ < NKS; ++s_) {     // 16 positions per step: tile row s / (TW / 16), columns 16 (s % (TW / 16)) ..
       const int r = s_ / (TW / 16), c0 = 16 * (s_ % (TW / 16));
       const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)(abase + (16 * s_) * 128));
       const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)(abase + (16 * s_ + 4) * 128));
       const bf16x8 a = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+      if constexpr (BIAS) { if (bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, accb, 0, 0, 0); }
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          const char* bp = bbase[kw][(r + kh) & 1] + ((r + kh) * PW + c0 + kw) * 128;
+          // compile-time part of the patch row: C = (S r + kh) PW + S c0 + kw; its bit 1 (S = 1: of the row term alone, the kw part is in lanebit)
+          constexpr int dummy = 0; (void)dummy;
+          const int crow = (S * r + kh) * PW + S * c0 + kw;
+          const int par = S == 1 ? ((((S * r + kh) * PW + c0) >> 1) & 1) : ((crow >> 1) & 1);
+          const char* bp = bbase[kw][par] + crow * 128;
           const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)(bp));
-          const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)(bp + 4 * 128));
+          const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)(bp + S * 4 * 128));
           const bf16x8 b = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
           acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[kh * 3 + kw], 0, 0, 0);
         }
@@ -442,6 +461,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_halo_kernel(const HaloWg
       const int co = (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
       atomicAdd(wsb + ((size_t)co * 9 + t) * Ci, acc[t][j]);
     }
+  if (BIAS && bias && nb == 0 && (lane & 31) == 0) {   // every column of the all-ones product holds the sums: one lane per row half writes them
+#pragma unroll
+    for (int j = 0; j < 16; ++j) atomicAdd(dbias + cob * 64 + mb * 32 + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5), accb[j]);
+  }
 }
 
 static std::atomic<int>& halo_wgrad_mode() {
@@ -470,17 +493,22 @@ int conv_halo_launch(const HaloConvArgs& a, int kind, hipStream_t stream) {
   return 1;
 }
 
-// 3 x 3 / stride 1 / padding 1 weight gradient into the packed workspace ws [Co][9][Ci] (zero on entry); 1 = taken
-int conv_halo_wgrad_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, hipStream_t stream) {
+// 3 x 3 / padding 1 / stride 1 or 2 weight gradient into the packed workspace ws [Co][9][Ci] (zero on entry), dbias += column sums of dy; 1 = taken
+int conv_halo_wgrad_launch(const void* x, const void* dy, float* ws, float* dbias, int N, int H, int W, int Ho, int Wo, int stride, int Ci, int Co,
+                           hipStream_t stream) {
   const int mode = halo_wgrad_mode().load(std::memory_order_relaxed);
-  if (mode == 0 || (Ci & 63) || (Co & 63)) return 0;
-  const long long big = (long long)N * H * W * (Ci > Co ? Ci : Co) * 2;
-  if (big >= (1ll << 31)) return 0;
-  // tile shape by the share of tile positions that lie inside the image
-  const double u0 = (double)H * W / ((double)cdiv(H, 8) * 8 * cdiv(W, 32) * 32), u1 = (double)H * W / ((double)cdiv(H, 16) * 16 * cdiv(W, 16) * 16);
+  if (mode == 0 || (Ci & 63) || (Co & 63) || (stride != 1 && stride != 2)) return 0;
+  if (Ho != (H + 2 - 3) / stride + 1 || Wo != (W + 2 - 3) / stride + 1) return 0;
+  if ((long long)N * H * W * Ci * 2 >= (1ll << 31) || (long long)N * Ho * Wo * Co * 2 >= (1ll << 31)) return 0;
+  // tile shape by the share of tile positions that lie inside the (output) image
+  const double u0 = (double)Ho * Wo / ((double)cdiv(Ho, 8) * 8 * cdiv(Wo, 32) * 32), u1 = (double)Ho * Wo / ((double)cdiv(Ho, 16) * 16 * cdiv(Wo, 16) * 16);
+  const double u2 = (double)Ho * Wo / ((double)cdiv(Ho, 8) * 8 * cdiv(Wo, 16) * 16);
   const bool sq = u1 > u0;
-  if (mode == 1 && (sq ? u1 : u0) < 0.5) return 0;          // small maps (7 x 7): most of every tile would be padding
-  const int tiles_h = cdiv(H, sq ? 16 : 8), tiles_w = cdiv(W, sq ? 16 : 32);
+  const double util = stride == 2 ? u2 : (sq ? u1 : u0);
+  if (mode == 1 && util < 0.5) return 0;                    // small maps (7 x 7): most of every tile would be padding
+  if (mode == 1 && stride == 2 && Ho * Wo < 28 * 28 / 2) return 0;     // stride 2 below 28 x 28 outputs: wgrad_kernel is as fast (14^2 -> 7^2: 106 vs 129 us)
+  const int th = stride == 2 ? 8 : (sq ? 16 : 8), tw = stride == 2 ? 16 : (sq ? 16 : 32);
+  const int tiles_h = cdiv(Ho, th), tiles_w = cdiv(Wo, tw);
   const long long nt = (long long)N * tiles_h * tiles_w;
   const int nob = (Ci >> 6) * (Co >> 6);
   // splits: a multiple of 8 (one group of consecutive splits per XCD), about one workgroup per CU, at least 4 tiles per split
@@ -489,8 +517,16 @@ int conv_halo_wgrad_launch(const void* x, const void* dy, float* ws, int N, int 
   if (mode == 1 && nt < 4ll * nsplit) return 0;
   if (nt >= (1ll << 30)) return 0;
   HaloWgradArgs a{x, dy, ws, N, H, W, Ci, Co};
-  if (sq) hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<16, 16>), dim3(nsplit * nob), dim3(256), 0, stream, a, tiles_h, tiles_w, (int)nt, nsplit);
-  else hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<8, 32>), dim3(nsplit * nob), dim3(256), 0, stream, a, tiles_h, tiles_w, (int)nt, nsplit);
+  const dim3 grid(nsplit * nob);
+#define SV_HALO_WG(TH_, TW_, S_)                                                                                                                           \
+  do {                                                                                                                                                   \
+    if (dbias) hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<TH_, TW_, S_, true>), grid, dim3(256), 0, stream, a, Ho, Wo, tiles_h, tiles_w, (int)nt, nsplit, dbias); \
+    else hipLaunchKernelGGL((conv3x3_wgrad_halo_kernel<TH_, TW_, S_, false>), grid, dim3(256), 0, stream, a, Ho, Wo, tiles_h, tiles_w, (int)nt, nsplit, dbias);      \
+  } while (0)
+  if (stride == 2) SV_HALO_WG(8, 16, 2);
+  else if (sq) SV_HALO_WG(16, 16, 1);
+  else SV_HALO_WG(8, 32, 1);
+#undef SV_HALO_WG
   halo_launches.fetch_add(1, std::memory_order_relaxed);
   return 1;
 }

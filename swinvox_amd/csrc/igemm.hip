@@ -1929,12 +1929,12 @@ extern "C" int sv_conv_wgrad(const void* anchor, int lda, const void* gathered, 
   a.dbias = dbias;
   a.out = a.direct ? dw : workspace;
   if (!a.direct) (void)hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)g->Co * Kout, s);
-  // 3 x 3 / stride 1 / padding 1 with 64 k channels on both sides and bf16 storage: the halo-tile weight gradient (conv_halo.hip) fills the
+  // 3 x 3 / stride 1 or 2 / padding 1 with 64 k channels on both sides and bf16 storage: the halo-tile weight gradient (conv_halo.hip) fills the
   // packed workspace; the unpack below is shared
-  if (!a.direct && !dbias && math == SV_MATH_BF16 && act == SV_BF16 && g->kd == 1 && g->kh == 3 && g->kw == 3 && g->sd == 1 && g->sh == 1 && g->sw == 1 &&
-      g->pd == 0 && g->ph == 1 && g->pw == 1 && g->Di == 1 && g->Do == 1 && g->Hi == g->Ho && g->Wi == g->Wo && cg_valid == g->Ci && lda == g->Co &&
+  if (!a.direct && math == SV_MATH_BF16 && act == SV_BF16 && g->kd == 1 && g->kh == 3 && g->kw == 3 && g->sd == 1 && g->sh == g->sw &&
+      g->pd == 0 && g->ph == 1 && g->pw == 1 && g->Di == 1 && g->Do == 1 && cg_valid == g->Ci && lda == g->Co &&
       g->ldi == g->Ci && (((uintptr_t)anchor | (uintptr_t)gathered) & 15) == 0 &&
-      conv_halo_wgrad_launch(gathered, anchor, workspace, g->N, g->Hi, g->Wi, g->Ci, g->Co, s)) {
+      conv_halo_wgrad_launch(gathered, anchor, workspace, dbias, g->N, g->Hi, g->Wi, g->Ho, g->Wo, g->sh, g->Ci, g->Co, s)) {
     const long long total = (long long)g->Co * cg_valid * taps;
     int blocks = cdiv(total, 256); if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(blocks), dim3(256), 0, s, workspace, dw, g->Co, g->Ci, cg_valid, taps);

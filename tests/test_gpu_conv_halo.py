@@ -137,33 +137,40 @@ def test_calls_the_kernels_do_not_take_stay_on_the_engine(dev, bf16_mode):
         assert bool(torch.isfinite(out.float()).all())
 
 
-@pytest.mark.parametrize("n,H,W,ci,co", [(20, 56, 56, 64, 64), (6, 28, 28, 128, 128), (4, 14, 14, 256, 256), (3, 45, 70, 64, 128), (2, 8, 32, 128, 64), (1, 5, 9, 64, 64)])
-def test_conv3x3_weight_gradient_halo(dev, bf16_mode, n, H, W, ci, co):
-    """Halo-tile weight gradient of the 3 x 3 / stride 1 convolutions (channel counts multiples of 64) against torch autograd on
-    bf16-representable operands and against wgrad_kernel on the same call; twice (the workspace is zeroed per call)."""
-    g = torch.Generator().manual_seed(n * 1000 + H * 10 + W + ci)
+@pytest.mark.parametrize("n,H,W,ci,co,stride,bias", [(20, 56, 56, 64, 64, 1, False), (6, 28, 28, 128, 128, 1, False), (4, 14, 14, 256, 256, 1, True),
+                                                      (3, 45, 70, 64, 128, 1, False), (2, 8, 32, 128, 64, 1, True), (1, 5, 9, 64, 64, 1, False),
+                                                      (6, 56, 56, 64, 64, 2, True), (4, 28, 28, 256, 256, 2, True), (3, 45, 71, 128, 64, 2, False),
+                                                      (2, 14, 14, 64, 128, 2, True), (1, 6, 9, 64, 64, 2, False)])
+def test_conv3x3_weight_gradient_halo(dev, bf16_mode, n, H, W, ci, co, stride, bias):
+    """Halo-tile weight gradient of the 3 x 3 / padding 1 convolutions of stride 1 and 2 (channel counts multiples of 64), with and without the
+    bias gradient, against torch autograd on bf16-representable operands and against wgrad_kernel on the same call; twice (the workspace
+    is zeroed per call)."""
+    g = torch.Generator().manual_seed(n * 1000 + H * 10 + W + ci + stride)
     x = torch.randn(n, ci, H, W, generator=g).bfloat16().float()
     w = (torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)).requires_grad_(True)
-    y = F.conv2d(x, w, None, stride=1, padding=1)
+    b = torch.zeros(co, requires_grad=True)
+    y = F.conv2d(x, w, b, stride=stride, padding=1)
     dy = torch.randn(y.shape, generator=g).bfloat16().float()
     y.backward(dy)
-    sp = ConvSpec.conv2d(ci, co, 3, 1, 1)
+    sp = ConvSpec.conv2d(ci, co, 3, stride, 1)
     xd, dyd = cl(x).to(dev).bfloat16(), cl(dy).to(dev).bfloat16()
 
     def wgrad():
-        dw = torch.zeros(co, ci, 3, 3, device=dev)
-        sp.wgrad(dyd, xd, n, (1, H, W), dw)
-        return dw
+        dw, db = torch.zeros(co, ci, 3, 3, device=dev), torch.zeros(co, device=dev)
+        sp.wgrad(dyd, xd, n, (1, H, W), dw, db=db if bias else None)
+        return dw, db
 
     outs = []
     for mode in (2, 2, 0):
         ops.set_conv_halo_wgrad(mode)
         n0 = int(hip.load().sv_conv_halo_launches())
-        dw = wgrad()
+        dw, db = wgrad()
         torch.cuda.synchronize()
         assert int(hip.load().sv_conv_halo_launches()) - n0 == (1 if mode else 0)
-        outs.append(dw)
+        outs.append((dw, db))
     ops.set_conv_halo_wgrad(1)
-    for dw in outs:
+    for dw, db in outs:
         assert rel(dw, w.grad) < 2e-3, rel(dw, w.grad)          # fp32 sums of products of bf16 operands: only the summation order differs
-    assert rel(outs[0], outs[2]) < 1e-3 and rel(outs[0], outs[1]) < 1e-4
+        if bias:
+            assert rel(db, b.grad) < 1e-4
+    assert rel(outs[0][0], outs[2][0]) < 1e-3 and rel(outs[0][0], outs[1][0]) < 1e-4
