@@ -35,6 +35,23 @@ for name, sp, H, ci, k in (("3x3 64->64 @56", ConvSpec.conv2d(64, 64, 3, 1, 1), 
             td = timeit(lambda: sp.dgrad(dy, n, (1, H, H), wd, dx))
             line += f"   data gradient {td:7.1f} us ({flops / td / 1e6:6.1f} TF/s)"
         print(line)
+# ---- 3 x 3 / stride 1 with 128 / 256 channels: gather engine against the blocked halo kernel
+for H, C in ((28, 128), (14, 256)):
+    sp = ConvSpec.conv2d(C, C, 3, 1, 1)
+    M = n * H * H
+    x = torch.randn(M, C, device=dev).bfloat16()
+    dy = torch.randn(M, C, device=dev).bfloat16()
+    w = torch.randn(C, C, 3, 3, device=dev) / math.sqrt(9 * C)
+    wf, wd = ops.pack_one(sp, w, "f"), ops.pack_one(sp, w, "d")
+    out, dx = ops.empty(M, C, device=dev), ops.empty(M, C, device=dev)
+    stats = torch.zeros(ops.BN_SLOTS, 2 * C, dtype=torch.float64, device=dev)
+    flops = 2.0 * M * 9 * C * C
+    for mode in (0, 2):
+        ops.set_conv_halo(mode)
+        tf = timeit(lambda: sp.forward(x, n, (1, H, H), wf, out, stats=stats))
+        td = timeit(lambda: sp.dgrad(dy, n, (1, H, H), wd, dx))
+        print(f"3x3 {C}->{C} @{H}  mode {mode}: forward+stats {tf:7.1f} us ({flops / tf / 1e6:6.1f} TF/s)   data gradient {td:7.1f} us ({flops / td / 1e6:6.1f} TF/s)")
+ops.set_conv_halo(1)
 # ---- weight gradient of the 3 x 3 / stride 1 convolutions (sv_conv_wgrad): wgrad_kernel against the halo-tile kernel
 for H, C, st in ((56, 64, 1), (28, 128, 1), (14, 256, 1), (7, 256, 1), (56, 256, 2), (28, 256, 2), (56, 128, 2), (14, 256, 2)):
     sp = ConvSpec.conv2d(C, C, 3, st, 1)

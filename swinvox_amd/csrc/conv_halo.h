@@ -17,6 +17,9 @@ struct HaloConvArgs {
 // kind: 0 = 3 x 3, padding 1, CI = 64;  1 = 4 x 4, padding (2, 1), CI = 16 (the ResNet stem on the space-to-depth image)
 int conv_halo_launch(const HaloConvArgs& a, int kind, hipStream_t stream);
 bool conv_halo_enabled();
+// the same convolution (3 x 3 / stride 1 / padding 1, plain store + optional statistics) with Ci, Co multiples of 64 up to 512: work items of 256
+// positions x 64 output channels with a K loop over blocks of 64 input channels; w = the [Co][9][Ci] pack (data-gradient pack with flip = 1)
+int conv_halo_blocked_launch(const void* x, const void* w, void* y, double* stats, int N, int H, int W, int Ci, int Co, int flip, hipStream_t stream);
 
 // 3 x 3 / padding 1 / stride 1 or 2 weight gradient (Ci, Co multiples of 64, rows of exactly Ci / Co elements) into the packed workspace
 // ws [Co][9][Ci] fp32 (zero on entry), dbias (optional) += column sums of dy; 1 = taken, 0 = not this kernel's shape or switched off

@@ -472,6 +472,220 @@ static std::atomic<int>& halo_wgrad_mode() {
   return m;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3 x 3 / stride 1 / padding 1 with MORE than 64 channels (conv2 of the layer2 / layer3 bottlenecks: 128 and 256 channels), forward and data
+// gradient.  The weights no longer fit in LDS (9 x 256 x 256 bf16 = 1.1 MB), so a work item is (tile of 256 positions, block of 64 output
+// channels) and its K loop runs over blocks of 64 INPUT channels: per block the [9][64][64] weight slice (72 KB) and the 64-channel slice of the
+// patch (43-47 KB) go global -> registers (prefetched under the previous block's 144 MFMAs per wave) -> LDS, and the contraction of
+// conv_halo_kernel runs on them; the accumulators live across the blocks.  Per MFLOP that is 6.2 KB of L2 -> LDS fill against 15 KB for the gather
+// engine's 128 x 128 tile (which stages the activation tile once per tap).  Items are drawn at run time, the output blocks of a tile
+// consecutively (they share the patch in L2).  Epilogue and statistics as in conv_halo_kernel, on the item's 128-byte piece of each output row.
+// TH x TW = 8 x 32 or 16 x 16 as in the weight gradient (14 x 14 maps fill 77 % of a 16 x 16 tile, 38 % of an 8 x 32 one).
+// ------------------------------------------------------------------------------------------------
+struct HaloBlockedArgs {
+  const void* x; const void* w; void* y; double* stats;
+  int N, H, W, Ci, Co, flip;
+};
+
+template <int TH, int TW>
+__global__ __launch_bounds__(256, 1) void conv3x3_halo_blocked_kernel(const HaloBlockedArgs p, int tiles_h, int tiles_w, int nitems, int* __restrict__ ctr) {
+  static_assert(TH * TW == 256 && (TW == 32 || TW == 16), "256 positions per tile");
+  constexpr int PW = TW + 2, NPOS = (TH + 2) * PW, PROWB = 144, NCH = NPOS * 8, NLD = (NCH + 255) / 256, NWL = 9 * 64 * 8 / 256;
+  constexpr int W_BYTES = 9 * 64 * 128, PATCH_BYTES = (NPOS * PROWB + 127) / 128 * 128, STAGE_BYTES = 4 * 4096;
+  constexpr int RPB = 32 / TW;                 // tile rows per block of 32 positions (1 or 2)
+  __shared__ __attribute__((aligned(1024))) char smem[W_BYTES + PATCH_BYTES + STAGE_BYTES + 16];
+  const __bf16* __restrict__ Wt = static_cast<const __bf16*>(p.w);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kg = lane >> 5;
+  const int H = p.H, Wd = p.W, Ci = p.Ci, Co = p.Co, nci = Ci >> 6, nco = Co >> 6;
+  char* Wl = smem;
+  char* Pl = smem + W_BYTES;
+  char* Sl = smem + W_BYTES + PATCH_BYTES + wave * 4096;
+  int* mbox = reinterpret_cast<int*>(smem + W_BYTES + PATCH_BYTES + STAGE_BYTES);
+
+  // ---- item scheduler (conv_halo_kernel's): 8 contiguous chunks of the item space, one per XCD; ctr[8] counts finished workgroups
+  const int xcd = blockIdx.x & 7, cq = nitems >> 3, cr = nitems & 7;
+  const int cbase = xcd * cq + (xcd < cr ? xcd : cr), csize = cq + (xcd < cr ? 1 : 0);
+  if (tid == 0) {
+    const int v0 = atomicAdd(ctr + xcd, 1), v1 = atomicAdd(ctr + xcd, 1);
+    mbox[0] = v0 < csize ? cbase + v0 : -1;
+    mbox[1] = v1 < csize ? cbase + v1 : -1;
+  }
+  __syncthreads();
+  int cur = __builtin_amdgcn_readfirstlane(mbox[0]), nxt = __builtin_amdgcn_readfirstlane(mbox[1]);
+  auto finish = [&]() {
+    if (atomicAdd(ctr + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) ctr[i] = 0;
+    }
+  };
+  if (cur < 0) { if (tid == 0) finish(); return; }
+
+  const unsigned xbytes = (unsigned)p.N * H * Wd * Ci * 2, ybytes = (unsigned)p.N * H * Wd * Co * 2, wbytes = (unsigned)Co * 9 * Ci * 2;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wt), 0, wbytes, 0x00020000);
+  const int tpi = tiles_h * tiles_w;
+  auto origin = [&](int item, int& n, int& h0, int& w0, int& cob) {
+    const int t = item / nco;
+    cob = item - t * nco;
+    n = t / tpi;
+    const int r = t - n * tpi, th = r / tiles_w;
+    h0 = th * TH; w0 = (r - th * tiles_w) * TW;
+  };
+  // per-thread constants: patch chunks (position row / column, byte offset relative to the tile origin) and weight chunks (row r of the
+  // slice = output channel, tap, 16-byte chunk c -> LDS slot of the [tap slot][r][64] image, source offset relative to the slice origin)
+  int cpr[NLD], cpc[NLD];
+  unsigned crel[NLD], wrel[NWL];
+  int wdst[NWL];
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int c = tid + 256 * j, pp = c >> 3, sc = c & 7;
+    cpr[j] = pp / PW - 1; cpc[j] = pp % PW - 1;
+    crel[j] = (unsigned)(((cpr[j] * Wd + cpc[j]) * Ci + sc * 8) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < NWL; ++j) {
+    const int id = tid + 256 * j, c = id & 7, rt = id >> 3, t = rt % 9, r = rt / 9;
+    const int ts = p.flip ? 8 - t : t;
+    wrel[j] = (unsigned)(((r * 9 + t) * Ci + c * 8) * 2);
+    wdst[j] = (ts * 64 + r) * 128 + ((c ^ hc_swz<64>(r)) << 4);
+  }
+  u32x4 pre[NLD], wpre[NWL];
+  auto load_block = [&](int item, int cib) {
+    int n, h0, w0, cob;
+    origin(item, n, h0, w0, cob);
+    const unsigned base = (unsigned)((n * H + h0) * Wd + w0) * Ci * 2 + cib * 128;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const bool ok = (unsigned)(h0 + cpr[j]) < (unsigned)H && (unsigned)(w0 + cpc[j]) < (unsigned)Wd;
+      pre[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, (base + crel[j]) | ((unsigned)!ok << 31), 0, 0);
+    }
+    const unsigned wbase = (unsigned)(cob * 64) * 9 * Ci * 2 + cib * 128;
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) wpre[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, wbase + wrel[j], 0, 0);
+  };
+  auto store_block = [&]() {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int c = tid + 256 * j;
+      if (NCH % 256 == 0 || c < NCH) *reinterpret_cast<u32x4*>(Pl + (c >> 3) * PROWB + (c & 7) * 16) = pre[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) *reinterpret_cast<u32x4*>(Wl + wdst[j]) = wpre[j];
+  };
+
+  double sd[4] = {0.0, 0.0, 0.0, 0.0};
+  const int swa = hc_swz<64>(ln);
+  const char* pa = Wl + ln * 128;
+  // block nb of the wave = 32 positions: tile rows (4 w + RPB nb) .. , position ln -> row ln / TW, column ln % TW
+  const char* pq[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) pq[nb] = Pl + (((2 * wave + nb) * RPB + ln / TW) * PW + ln % TW) * PROWB + kg * 16;
+  int aoff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) aoff[ks] = ((2 * ks + kg) ^ swa) << 4;
+
+  load_block(cur, 0);
+  while (true) {
+    int drawn;
+    if (tid == 0) drawn = atomicAdd(ctr + xcd, nxt >= 0 ? 1 : 0);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[mb][nb][j] = 0.f;
+    for (int cib = 0; cib < nci; ++cib) {
+      __syncthreads();                   // everyone is done with the previous slices
+      store_block();
+      __syncthreads();
+      // next slices: the next input-channel block of this item, or the first one of the next item (the last item re-reads its own)
+      if (cib + 1 < nci) load_block(cur, cib + 1);
+      else load_block(nxt >= 0 ? nxt : cur, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 fa[2][2], fb[2][2];
+      auto frags = [&](int step, bf16x8* a, bf16x8* b) {
+        const int t = step >> 2, ks = step & 3, kh = t / 3, kw = t - kh * 3;
+        a[0] = *reinterpret_cast<const bf16x8*>(pa + t * 64 * 128 + aoff[ks]);
+        b[0] = *reinterpret_cast<const bf16x8*>(pq[0] + (kh * PW + kw) * PROWB + ks * 32);
+        a[1] = *reinterpret_cast<const bf16x8*>(pa + (t * 64 + 32) * 128 + aoff[ks]);
+        b[1] = *reinterpret_cast<const bf16x8*>(pq[1] + (kh * PW + kw) * PROWB + ks * 32);
+      };
+      frags(0, fa[0], fb[0]);
+#pragma unroll
+      for (int step = 0; step < 36; ++step) {
+        const int c = step & 1;
+        if (step + 1 < 36) frags(step + 1, fa[c ^ 1], fb[c ^ 1]);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][1], fb[c][1], acc[1][1], 0, 0, 0);
+        if (step + 1 < 36) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (step + 1 < 36) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      }
+    }
+    if (tid == 0) mbox[0] = (nxt >= 0 && drawn < csize) ? cbase + drawn : -1;
+
+    // ---- epilogue of `cur` (conv_halo_kernel's, on the 64 output channels of the item)
+    int n, h0, w0, cob;
+    origin(cur, n, h0, w0, cob);
+    const int ncol = min(TW, Wd - w0);
+    f32x2 sa = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int row0 = h0 + (2 * wave + nb) * RPB;             // first tile row of the block
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int jg = 0; jg < 4; ++jg) {
+          bf16x4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = (__bf16)acc[mb][nb][jg * 4 + i];
+          *reinterpret_cast<bf16x4*>(Sl + ln * 128 + (((mb * 4 + jg) ^ (ln & 7)) << 4) + kg * 8) = o;
+        }
+      }
+#pragma unroll
+      for (int itr = 0; itr < 4; ++itr) {
+        const int q = itr * 8 + (lane >> 3), c8 = lane & 7, row = row0 + q / TW, col = w0 + q % TW;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(Sl + q * 128 + ((c8 ^ (q & 7)) << 4));
+        const unsigned off = ((unsigned)((n * H + row) * Wd + col) * Co * 2 + cob * 128 + c8 * 16) | ((unsigned)!(row < H && col < Wd) << 31);
+        __builtin_amdgcn_raw_buffer_store_b128(v, yr, off, 0, 0);
+      }
+      if (p.stats) {                     // lane (kg, cp = ln): channels 2 cp, 2 cp + 1 over positions 16 kg .. 16 kg + 15 of the block
+        const int prow = row0 + (TW == 16 ? kg : 0), pc0 = TW == 16 ? 0 : 16 * kg;
+        if (prow < H) {
+          const char* srow = Sl + kg * 16 * 128 + (ln & 3) * 4;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const unsigned u = *reinterpret_cast<const unsigned*>(srow + i * 128 + ((((ln >> 2) ^ i) & 7) << 4));
+            const float m = pc0 + i < ncol ? 1.f : 0.f;
+            const f32x2 v = {__uint_as_float(u << 16) * m, __uint_as_float(u & 0xffff0000u) * m};
+            sa += v; sb += v * v;
+          }
+        }
+      }
+    }
+    if (p.stats) {
+      sd[0] += (double)sa[0]; sd[1] += (double)sb[0]; sd[2] += (double)sa[1]; sd[3] += (double)sb[1];
+      // one item = one block of output channels: the sums go out per item (the next item of the workgroup may be another block)
+      double* st = p.stats + (size_t)((blockIdx.x * 8 + wave * 2 + kg) % SV_BN_SLOTS) * 2 * Co + cob * 64;
+      atomicAdd(st + 2 * ln, sd[0]);
+      atomicAdd(st + Co + 2 * ln, sd[1]);
+      atomicAdd(st + 2 * ln + 1, sd[2]);
+      atomicAdd(st + Co + 2 * ln + 1, sd[3]);
+      sd[0] = sd[1] = sd[2] = sd[3] = 0.0;
+    }
+    __syncthreads();                     // the mailbox is posted, every wave is past its reads of it
+    if (nxt < 0) break;
+    cur = nxt;
+    nxt = __builtin_amdgcn_readfirstlane(mbox[0]);
+  }
+  if (tid == 0) finish();
+}
+
 static std::atomic<long long> halo_launches{0};
 bool conv_halo_enabled() { return halo_mode().load(std::memory_order_relaxed) != 0; }
 
@@ -489,6 +703,27 @@ int conv_halo_launch(const HaloConvArgs& a, int kind, hipStream_t stream) {
     hipLaunchKernelGGL((conv_halo_kernel<64, 3, 3, 1, 1>), dim3(256), dim3(256), 0, stream, a, tiles_h, tiles_w, ntiles, ctr);
   else   // 32 KB of weights + 18 KB patch + 16 KB staging: two workgroups per CU - one's epilogue runs under the other's MFMAs
     hipLaunchKernelGGL((conv_halo_kernel<16, 4, 4, 2, 2>), dim3(512), dim3(256), 0, stream, a, tiles_h, tiles_w, ntiles, ctr);
+  halo_launches.fetch_add(1, std::memory_order_relaxed);
+  return 1;
+}
+
+// 3 x 3 / stride 1 / padding 1 with Ci, Co multiples of 64 (not both 64: that is conv_halo_launch's resident-weights kernel); 1 = taken
+int conv_halo_blocked_launch(const void* x, const void* w, void* y, double* stats, int N, int H, int W, int Ci, int Co, int flip, hipStream_t stream) {
+  const int mode = halo_mode().load(std::memory_order_relaxed);
+  static const int blocked_on = [] { const char* v = getenv("SV_CONV_HALO_BLOCKED"); return v ? atoi(v) : 1; }();
+  if (mode == 0 || !blocked_on || (Ci & 63) || (Co & 63) || Ci > 512 || Co > 512) return 0;
+  if ((long long)N * H * W * (Ci > Co ? Ci : Co) * 2 >= (1ll << 31)) return 0;
+  const double u0 = (double)H * W / ((double)cdiv(H, 8) * 8 * cdiv(W, 32) * 32), u1 = (double)H * W / ((double)cdiv(H, 16) * 16 * cdiv(W, 16) * 16);
+  const bool sq = u1 > u0;
+  if (mode == 1 && (sq ? u1 : u0) < 0.5) return 0;
+  const int tiles_h = cdiv(H, sq ? 16 : 8), tiles_w = cdiv(W, sq ? 16 : 32);
+  const long long ni = (long long)N * tiles_h * tiles_w * (Co >> 6);
+  if ((mode == 1 && ni < 1024) || ni >= (1ll << 30)) return 0;
+  int* ctr = tile_draw_counters();
+  if (!ctr) return 0;
+  HaloBlockedArgs a{x, w, y, stats, N, H, W, Ci, Co, flip};
+  if (sq) hipLaunchKernelGGL((conv3x3_halo_blocked_kernel<16, 16>), dim3(256), dim3(256), 0, stream, a, tiles_h, tiles_w, (int)ni, ctr);
+  else hipLaunchKernelGGL((conv3x3_halo_blocked_kernel<8, 32>), dim3(256), dim3(256), 0, stream, a, tiles_h, tiles_w, (int)ni, ctr);
   halo_launches.fetch_add(1, std::memory_order_relaxed);
   return 1;
 }

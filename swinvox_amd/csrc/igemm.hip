@@ -1554,13 +1554,15 @@ int* tile_draw_counters() { return gemm_wide_counters(); }
 static int try_halo(const void* in, const void* w, void* out, const sv_geom* g, const sv_epilogue* e, int math, int act_dtype, bool dgrad,
                     hipStream_t s) {
   if (math != SV_MATH_BF16 || act_dtype != SV_BF16 || !conv_halo_enabled()) return 0;
-  if (g->Co != 64 || g->kd != 1 || g->Di != 1 || g->Do != 1 || g->sd != 1 || g->sh != 1 || g->sw != 1 || g->pd != 0) return 0;
+  if ((g->Co & 63) || g->kd != 1 || g->Di != 1 || g->Do != 1 || g->sd != 1 || g->sh != 1 || g->sw != 1 || g->pd != 0) return 0;
   if (g->Hi != g->Ho || g->Wi != g->Wo || g->ldi != g->Ci) return 0;
-  if (e->bias || e->residual || e->row_scale || e->pre_act || e->act != SV_ACT_NONE || e->act_grad_src || e->ldc != 64 || e->col_off != 0) return 0;
+  if (e->bias || e->residual || e->row_scale || e->pre_act || e->act != SV_ACT_NONE || e->act_grad_src || e->ldc != g->Co || e->col_off != 0) return 0;
   if (((uintptr_t)in | (uintptr_t)w | (uintptr_t)out) & 15) return 0;
   int kind;
-  if (g->kh == 3 && g->kw == 3 && g->ph == 1 && g->pw == 1 && g->Ci == 64) kind = 0;
-  else if (!dgrad && g->kh == 4 && g->kw == 4 && g->ph == 2 && g->pw == 2 && g->Ci == 16) kind = 1;
+  if (g->kh == 3 && g->kw == 3 && g->ph == 1 && g->pw == 1 && g->Ci == 64 && g->Co == 64) kind = 0;
+  else if (g->kh == 3 && g->kw == 3 && g->ph == 1 && g->pw == 1 && !(dgrad && e->stats))      // more channels: blocks of 64 x 64 (conv_halo.hip)
+    return conv_halo_blocked_launch(in, w, out, e->stats, g->N, g->Hi, g->Wi, g->Ci, g->Co, dgrad ? 1 : 0, s);
+  else if (!dgrad && g->kh == 4 && g->kw == 4 && g->ph == 2 && g->pw == 2 && g->Ci == 16 && g->Co == 64) kind = 1;
   else return 0;
   if (dgrad && e->stats) return 0;
   HaloConvArgs a{in, w, out, e->stats, g->N, g->Hi, g->Wi, dgrad ? 1 : 0};

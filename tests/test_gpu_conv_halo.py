@@ -117,14 +117,14 @@ def test_stem_4x4_on_the_space_to_depth_image(dev, bf16_mode, n, H, W):
 
 
 def test_calls_the_kernels_do_not_take_stay_on_the_engine(dev, bf16_mode):
-    """bias, an activation, a residual, another channel count or stride: the gather engine keeps the call (mode 2 = every call the kernels can take)."""
+    """bias, an activation, a residual, a channel count that is no multiple of 64, another stride: the gather engine keeps the call (mode 2 = every call the kernels can take)."""
     ops.set_conv_halo(2)
     n, H = 2, 16
     x = torch.randn(n * H * H, 64, device=dev).bfloat16()
     cases = [(ConvSpec.conv2d(64, 64, 3, 1, 1), dict(bias=torch.zeros(64, device=dev))),
              (ConvSpec.conv2d(64, 64, 3, 1, 1), dict(act=ops.ACT_RELU)),
              (ConvSpec.conv2d(64, 64, 3, 1, 1), dict(residual=x, ldr=64)),
-             (ConvSpec.conv2d(64, 128, 3, 1, 1), {}),
+             (ConvSpec.conv2d(64, 96, 3, 1, 1), {}),
              (ConvSpec.conv2d(64, 64, 3, 2, 1), {})]
     for sp, epi in cases:
         w = torch.randn(sp.cout, 64, 3, 3, device=dev) / 24.0
@@ -174,3 +174,45 @@ def test_conv3x3_weight_gradient_halo(dev, bf16_mode, n, H, W, ci, co, stride, b
         if bias:
             assert rel(db, b.grad) < 1e-4
     assert rel(outs[0][0], outs[2][0]) < 1e-3 and rel(outs[0][0], outs[1][0]) < 1e-4
+
+
+@pytest.mark.parametrize("n,H,W,ci,co", [(40, 28, 28, 128, 128), (24, 14, 14, 256, 256), (3, 45, 70, 128, 64), (2, 17, 33, 64, 192), (1, 5, 9, 256, 128)])
+def test_conv3x3_blocked_forward_statistics_and_data_gradient(dev, bf16_mode, n, H, W, ci, co):
+    """3 x 3 / stride 1 with more than 64 channels (conv2 of the layer2 / layer3 bottlenecks): items of 256 positions x 64 output channels
+    with a K loop over blocks of 64 input channels - forward with statistics and data gradient against torch and against the gather engine."""
+    g = torch.Generator().manual_seed(n * 1000 + H * 10 + W + ci * 3 + co)
+    x = torch.randn(n, ci, H, W, generator=g).bfloat16().float().requires_grad_(True)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)).bfloat16().float().requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=1, padding=1)
+    dy = torch.randn(y.shape, generator=g).bfloat16().float()
+    y.backward(dy)
+    sp = ConvSpec.conv2d(ci, co, 3, 1, 1)
+    M = n * H * W
+    xd, dyd, wd = cl(x).to(dev).bfloat16(), cl(dy).to(dev).bfloat16(), w.detach().to(dev)
+    wf, wdg = ops.pack_one(sp, wd, "f"), ops.pack_one(sp, wd, "d")
+
+    def fwd():
+        out = ops.empty(M, co, device=dev)
+        stats = torch.zeros(ops.BN_SLOTS, 2 * co, dtype=torch.float64, device=dev)
+        sp.forward(xd, n, (1, H, W), wf, out, stats=stats)
+        return out, stats
+
+    def dgrad():
+        dx = ops.empty(M, ci, device=dev)
+        sp.dgrad(dyd, n, (1, H, W), wdg, dx)
+        return dx
+
+    for rep in range(2):
+        (out, stats), took = _run(sp, 2, fwd)
+        assert took == 1
+        assert rel(out, cl(y)) < 6e-3
+        st, o = stats.sum(0), out.float().cpu().double()
+        assert rel(st[:co], o.sum(0)) < 1e-4 and rel(st[co:], (o * o).sum(0)) < 1e-4
+        dx, took = _run(sp, 2, dgrad)
+        assert took == 1
+        assert rel(dx, cl(x.grad)) < 6e-3
+    (eout, estats), took = _run(sp, 0, fwd)
+    assert took == 0
+    edx, _ = _run(sp, 0, dgrad)
+    assert rel(out, eout) < 8e-3 and float((out.float() - eout.float()).abs().mean() / eout.float().abs().mean()) < 5e-4
+    assert rel(dx, edx) < 8e-3 and float((dx.float() - edx.float()).abs().mean() / edx.float().abs().mean()) < 5e-4
