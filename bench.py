@@ -329,7 +329,7 @@ def main():
                                 + ("; window-attention forward QK^T / PV on fp8 e4m3 MFMA operands (per-tile scales)" if args.fp8_attention else "")
                                 if args.math == "bf16" else "exact fp32 MFMA, fp32 storage")},
             "roofline": {"bound": "hbm" if hbm_bound else "mfma",
-                         "kernel": "implicit-GEMM contraction engine (igemm_kernel / gemm_dense_kernel / gemm_wide_kernel / conv_halo_kernel / wgrad_kernel / wgrad_wide_kernel: Linear/Conv/ConvTranspose fwd+dgrad+wgrad)",
+                         "kernel": "implicit-GEMM contraction engine (igemm_kernel / gemm_dense_kernel / gemm_wide_kernel / conv_halo / conv3x3_halo_blocked / conv3x3_wgrad_halo kernels / wgrad_kernel / wgrad_wide_kernel: Linear/Conv/ConvTranspose fwd+dgrad+wgrad)",
                          "achieved": r["GB/s"] if hbm_bound else r["TFLOP/s"], "peak": PEAK_HBM_GBS if hbm_bound else peak,
                          "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": (r["GB/s"] / PEAK_HBM_GBS) if hbm_bound else (r["TFLOP/s"] / peak),
                          "traffic": traffic, "traffic_source": traffic_src,

@@ -22,8 +22,9 @@ def family(name: str) -> str:
             if k in n:
                 return "fused Swin MLP: " + k
     if ("igemm_kernel" in n or ("wgrad_kernel" in n and "stencil" not in n) or "gemm_dense_kernel" in n or "gemm_wide_kernel" in n or "wgrad_wide_kernel" in n
-            or "conv_halo_kernel" in n):     # the halo-tile kernels run behind the same entry points (sv_conv_gather / sv_tconv_gather)
-        return "contraction engine (igemm_kernel + gemm_dense_kernel + gemm_wide_kernel + conv_halo_kernel + wgrad_kernel + wgrad_wide_kernel)"
+            or "conv_halo_kernel" in n or "conv3x3_halo_blocked_kernel" in n or "conv3x3_wgrad_halo_kernel" in n):
+        # (the halo-tile kernels run behind the same entry points: sv_conv_gather / sv_tconv_gather / sv_conv_wgrad)
+        return "contraction engine (igemm_kernel + gemm_dense_kernel + gemm_wide_kernel + halo-tile kernels + wgrad_kernel + wgrad_wide_kernel)"
     if "swin_attn_block_fwd" in n:
         return "fused Swin attention branch forward (swin_attn_block_fwd_kernel)"
     if "swin_attn_block_bwd" in n:
